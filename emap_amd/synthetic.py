@@ -1,0 +1,126 @@
+"""Deterministic synthetic inputs for the EMAP render hot path.
+
+There is no dataset or checkpoint in the build/benchmark environment, so every
+test, golden vector and benchmark uses the generators in this file:
+
+* ``udf_layer_dims`` / ``make_udf_state`` - a seeded (NumPy PCG64) UDF-MLP
+  state dict with the reference's geometric-init statistics
+  (reference ``src/models/udf_model.py:24-71``) plus an N(0, pert^2)
+  perturbation, in the reference's own state-dict key layout
+  (``lin{l}.bias``, ``lin{l}.parametrizations.weight.original0`` = g,
+  ``...original1`` = v), so the same dict loads into the reference
+  ``UDFNetwork`` (golden generation) and into ``emap_amd.UDFNetwork``.
+* ``make_rays`` - cameras on a radius-3 sphere looking at the origin, 60 degree
+  frustum, ``near``/``far`` as (N,1) tensors (reference ``render`` :700 branch).
+
+Only NumPy is used for the random streams so results do not depend on the
+torch version.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+
+def pe_dim(multires: int, d_in: int = 3) -> int:
+    """Embedding width 3 + 6*multires (reference embedder.py:14-29)."""
+    return d_in + 2 * d_in * multires if multires > 0 else d_in
+
+
+def udf_layer_dims(d_in=3, d_out=1, d_hidden=256, n_layers=8, skip_in=(4,), multires=10):
+    """[(out, in)] for lin0..lin{n_layers} (reference udf_model.py:24-45)."""
+    dims = [d_in] + [d_hidden] * n_layers + [d_out]
+    dims[0] = pe_dim(multires, d_in)
+    shapes = []
+    for l in range(len(dims) - 1):
+        out_dim = dims[l + 1] - dims[0] if (l + 1) in skip_in else dims[l + 1]
+        shapes.append((out_dim, dims[l]))
+    return shapes
+
+
+def make_udf_state(
+    d_in=3,
+    d_out=1,
+    d_hidden=256,
+    n_layers=8,
+    skip_in=(4,),
+    multires=10,
+    bias=0.5,
+    seed=42,
+    pert=0.02,
+    dtype=torch.float32,
+):
+    """Seeded state dict with geometric-init statistics + perturbation."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    shapes = udf_layer_dims(d_in, d_out, d_hidden, n_layers, skip_in, multires)
+    d0 = shapes[0][1]
+    n_lin = len(shapes)
+    state = {}
+    for l, (out_dim, in_dim) in enumerate(shapes):
+        if l == n_lin - 1:
+            v = rng.normal(np.sqrt(np.pi) / np.sqrt(in_dim), 1e-4, size=(out_dim, in_dim))
+            b = np.full((out_dim,), -bias)
+        elif multires > 0 and l == 0:
+            v = np.zeros((out_dim, in_dim))
+            v[:, :3] = rng.normal(0.0, np.sqrt(2) / np.sqrt(out_dim), size=(out_dim, 3))
+            b = np.zeros((out_dim,))
+        elif multires > 0 and l in skip_in:
+            v = rng.normal(0.0, np.sqrt(2) / np.sqrt(out_dim), size=(out_dim, in_dim))
+            v[:, -(d0 - 3):] = 0.0
+            b = np.zeros((out_dim,))
+        else:
+            v = rng.normal(0.0, np.sqrt(2) / np.sqrt(out_dim), size=(out_dim, in_dim))
+            b = np.zeros((out_dim,))
+        g = np.linalg.norm(v, axis=1, keepdims=True)
+        if pert > 0:
+            v = v + pert * rng.normal(size=v.shape)
+            b = b + pert * rng.normal(size=b.shape)
+            g = g * (1.0 + pert * rng.normal(size=g.shape))
+        state[f"lin{l}.bias"] = torch.tensor(b, dtype=dtype)
+        state[f"lin{l}.parametrizations.weight.original0"] = torch.tensor(g, dtype=dtype)
+        state[f"lin{l}.parametrizations.weight.original1"] = torch.tensor(v, dtype=dtype)
+    return state
+
+
+def make_rays(n_rays: int, seed: int = 1, near: float = 0.05, far: float = 6.0, radius: float = 3.0,
+              fov_deg: float = 60.0, n_cams: int = 4, dtype=torch.float32):
+    """Synthetic rays: (rays_o, rays_d, near(N,1), far(N,1), depth_scale(N,1))."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    cam_id = rng.integers(0, n_cams, size=n_rays)
+    # camera centres on the sphere
+    phi = rng.uniform(0, 2 * np.pi, size=n_cams)
+    cos_t = rng.uniform(-0.6, 0.6, size=n_cams)
+    sin_t = np.sqrt(1 - cos_t ** 2)
+    centres = radius * np.stack([sin_t * np.cos(phi), sin_t * np.sin(phi), cos_t], -1)
+    rays_o = centres[cam_id]
+    # camera frame: z looks at origin
+    fwd = -rays_o / np.linalg.norm(rays_o, axis=-1, keepdims=True)
+    up = np.array([0.0, 0.0, 1.0])
+    right = np.cross(fwd, up)
+    right /= np.linalg.norm(right, axis=-1, keepdims=True)
+    upv = np.cross(right, fwd)
+    t = np.tan(np.deg2rad(fov_deg) / 2)
+    u = rng.uniform(-t, t, size=(n_rays, 1))
+    v = rng.uniform(-t, t, size=(n_rays, 1))
+    d_cam = np.concatenate([u, v, np.ones_like(u)], -1)
+    d_cam /= np.linalg.norm(d_cam, axis=-1, keepdims=True)
+    rays_d = d_cam[:, 0:1] * right + d_cam[:, 1:2] * upv + d_cam[:, 2:3] * fwd
+    depth_scale = d_cam[:, 2:3]
+    to = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=dtype)
+    near_t = torch.full((n_rays, 1), near, dtype=dtype)
+    far_t = torch.full((n_rays, 1), far, dtype=dtype)
+    return to(rays_o), to(rays_d), near_t, far_t, to(depth_scale)
+
+
+def make_t_rand(n_rays: int, seed: int = 7, dtype=torch.float32):
+    """Per-ray jitter U(-0.5, 0.5) (stands in for the CPU torch.rand draw of render() :719)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return torch.tensor(rng.uniform(-0.5, 0.5, size=(n_rays, 1)), dtype=dtype)
+
+
+def make_true_edge(n_rays: int, seed: int = 11, dtype=torch.float32):
+    """Targets: Bernoulli(0.1) * U(0.5, 1)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    on = rng.uniform(size=(n_rays, 1)) < 0.1
+    val = rng.uniform(0.5, 1.0, size=(n_rays, 1))
+    return torch.tensor(on * val, dtype=dtype)

@@ -1,0 +1,178 @@
+"""Pins oracle/emap_oracle.py to the real reference through the committed golden vectors
+(tests/golden/*.npz, produced by tests/golden/make_goldens.py from /root/reference)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, t, net_state, NETS
+from oracle import emap_oracle as O
+
+
+def cfg_of(name, scale=1.0):
+    kw, _ = net_state(name)
+    return O.UDFConfig(d_in=kw["d_in"], d_out=kw["d_out"], d_hidden=kw["d_hidden"], n_layers=kw["n_layers"],
+                       skip_in=tuple(kw["skip_in"]), multires=kw["multires"], scale=scale, bias=kw["bias"])
+
+
+def close(a, b, rtol=1e-5, atol=1e-6):
+    a = torch.as_tensor(a); b = torch.as_tensor(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert torch.allclose(a, b, rtol=rtol, atol=atol), float((a - b).abs().max())
+
+
+def test_g1_positional_encoding():
+    g = load_golden("g1_pe")
+    x = t(g["x"])
+    for L in (10, 6):
+        pe = O.positional_encoding(x, L)
+        assert torch.equal(pe, t(g[f"pe_L{L}"]))  # same torch ops in the same order: bit-exact
+
+
+@pytest.mark.parametrize("name", list(NETS))
+def test_g2_mlp_value_and_gradient(name):
+    g = load_golden("g2_mlp")
+    kw, state = net_state(name)
+    wsum = np.array([float(v.double().abs().sum()) for v in state.values()])
+    np.testing.assert_allclose(wsum, g[f"{name}.wsum"], rtol=1e-12)  # same weights as when generated
+    cfg = cfg_of(name)
+    x = t(g["x"])
+    out, pe = O.udf_forward(state, cfg, x)
+    close(out, t(g[f"{name}.out"]), 1e-5, 1e-6)
+    close(pe, t(g[f"{name}.pe"]), 0, 0)
+    close(O.udf_value(state, cfg, x), t(g[f"{name}.udf"]), 1e-5, 1e-6)
+    ga = O.udf_gradient_autograd(state, cfg, x)
+    gref = t(g[f"{name}.grad"])
+    assert float((ga - gref).abs().max()) <= 2e-5 * float(gref.abs().max())
+    # analytic forward-mode restatement (what the HIP kernel does) == autograd of the reference
+    u, gr = O.udf_value_and_grad(state, cfg, x)
+    close(u, t(g[f"{name}.udf"]), 1e-5, 1e-6)
+    ref = t(g[f"{name}.grad"]).reshape(-1, 3)
+    assert float((gr - ref).abs().max()) <= 2e-4 * float(ref.abs().max())
+
+
+def test_g2_scale():
+    g = load_golden("g2_mlp")
+    _, state = net_state("d8w256L10")
+    cfg = cfg_of("d8w256L10", scale=1.5)
+    x = t(g["x"])
+    close(O.udf_value(state, cfg, x), t(g["scale1p5.udf"]), 1e-5, 1e-6)
+    u, gr = O.udf_value_and_grad(state, cfg, x)
+    ref = t(g["scale1p5.grad"]).reshape(-1, 3)
+    assert float((gr - ref).abs().max()) <= 2e-4 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("m", [10, 16])
+def test_g3_sample_pdf_indices_bit_exact(m):
+    g = load_golden("g3_sample_pdf")
+    s, inds = O.sample_pdf(t(g["bins"]), t(g["weights"]), m, return_inds=True)
+    assert torch.equal(inds, t(g[f"inds_m{m}"]))
+    assert torch.equal(s, t(g[f"samples_m{m}"]))
+
+
+def test_g4_upsample_and_merge():
+    g = load_golden("g4_upsample_step")
+    _, state = net_state("d8w256L10")
+    cfg = cfg_of("d8w256L10")
+    rays_o, rays_d = t(g["rays_o"]), t(g["rays_d"])
+    z, udf = t(g["z_vals"]), t(g["udf"])
+    sd = float(g["sample_dist"])
+    for i in range(2):
+        inv_s, beta, gamma = [float(v) for v in g[f"step{i}.params"]]
+        r = O.up_sample_unbias(rays_o, rays_d, z, udf, sd, 16, inv_s, beta, gamma, return_all=True)
+        assert torch.equal(r["inds"], t(g[f"step{i}.inds"]))
+        assert torch.equal(r["z_samples"], t(g[f"step{i}.z_new"]))
+        z2, udf2, index = O.cat_z_vals(state, cfg, rays_o, rays_d, z, r["z_samples"], udf, return_index=True)
+        assert torch.equal(index, t(g[f"step{i}.sort_index"]))
+        assert torch.equal(z2, t(g[f"step{i}.z_out"]))
+        close(udf2, t(g[f"step{i}.udf_out"]), 1e-5, 1e-6)
+        z, udf = t(g[f"step{i}.z_out"]), t(g[f"step{i}.udf_out"])
+
+
+RENDER_KEYS = ["udf", "edge", "weight_sum", "weight_sum_fg_bg", "depth", "variance", "beta", "gamma",
+               "normals", "gradients", "gradients_flip", "weights", "gradient_error",
+               "gradient_error_near_surface", "inside_sphere", "gradient_mag", "mid_z_vals", "dists"]
+G5 = {"c64_50_5": "d8w256L10", "c64_64_4": "d8w256L10", "c32_32_4_small": "d4w128L10", "c64_64_4_L6": "d8w256L6"}
+
+
+@pytest.mark.parametrize("case", list(G5))
+def test_g5_full_render(case):
+    g = load_golden("g5_render_" + case)
+    _, state = net_state(G5[case])
+    cfg = cfg_of(G5[case])
+    ns, ni, steps = [int(v) for v in g["cfg"]]
+    rcfg = O.RenderConfig(n_samples=ns, n_importance=ni, up_sample_steps=steps)
+    args = [t(g[k]) for k in ("rays_o", "rays_d", "near", "far", "depth_scale")]
+    var, bp, gp = torch.tensor([0.3]), torch.tensor([0.5]), torch.tensor([0.3])
+    trace = []
+    out = O.render(state, cfg, rcfg, *args, var, bp, gp, cos_anneal_ratio=1.0, flip_saturation=0.9, trace=trace)
+    for i in range(steps):
+        assert torch.equal(trace[i + 1]["z_vals"], t(g[f"z_after_step{i}"])), f"z after step {i}"
+    for k in RENDER_KEYS:
+        ref = t(g["out." + k])
+        got = out[k]
+        scale = float(ref.abs().max()) + 1e-12
+        err = float((got.reshape(ref.shape) - ref).abs().max())
+        assert err <= 2e-5 * scale + 1e-7, (k, err, scale)
+    out2 = O.render(state, cfg, rcfg, *args, var, bp, gp, cos_anneal_ratio=0.3, flip_saturation=0.0,
+                    background_rgb=torch.ones([1, 1]))
+    for k in ["edge", "depth", "weights", "normals", "gradient_error"]:
+        ref = t(g["out2." + k])
+        scale = float(ref.abs().max()) + 1e-12
+        assert float((out2[k].reshape(ref.shape) - ref).abs().max()) <= 2e-5 * scale + 1e-7, k
+    # the analytic (forward-mode) gradient path gives the same render
+    out3 = O.render(state, cfg, rcfg, *args, var, bp, gp, cos_anneal_ratio=1.0, flip_saturation=0.9,
+                    analytic_grad=True)
+    for k in ["edge", "depth", "weights", "gradient_error"]:
+        ref = t(g["out." + k])
+        scale = float(ref.abs().max()) + 1e-12
+        assert float((out3[k].reshape(ref.shape) - ref).abs().max()) <= 1e-4 * scale + 1e-7, k
+
+
+@pytest.mark.parametrize("ci", [0, 1, 2, 3])
+def test_g6_training_loss_and_grads(ci):
+    g = load_golden(f"g6_training_{ci}")
+    name = str(g["netname"])
+    _, state = net_state(name)
+    cfg = cfg_of(name)
+    ns, ni, steps = [int(v) for v in g["cfg"]]
+    rcfg = O.RenderConfig(n_samples=ns, n_importance=ni, up_sample_steps=steps)
+    ew, igr, igr_ns = [float(v) for v in g["weights3"]]
+    loss, edge_loss, grads, extra, out = O.loss_and_param_grads(
+        state, cfg, rcfg, t(g["rays_o"]), t(g["rays_d"]), t(g["near"]), t(g["far"]), t(g["depth_scale"]),
+        t(g["true_edge"]), torch.tensor([0.3]), torch.tensor([0.5]), torch.tensor([0.3]),
+        float(g["cos_anneal_ratio"]), float(g["flip_saturation"]), edge_weight=ew, igr_weight=igr,
+        igr_ns_weight=igr_ns)
+    close(loss, t(g["loss"]), 1e-5, 1e-7)
+    close(edge_loss, t(g["edge_loss"]), 1e-5, 1e-7)
+    for k, gr in grads.items():
+        ref = t(g["grad." + k])
+        scale = float(ref.abs().max()) + 1e-12
+        assert float((gr - ref).abs().max()) <= 1e-4 * scale + 1e-8, k
+    for k in ("variance", "beta", "gamma"):
+        ref = t(g["grad." + k])
+        assert float((extra[k] - ref).abs().max()) <= 1e-4 * float(ref.abs().max()) + 1e-8, k
+
+
+def test_g7_perturb_path():
+    g = load_golden("g7_perturb")
+    _, state = net_state("d4w128L10")
+    cfg = cfg_of("d4w128L10")
+    rcfg = O.RenderConfig(n_samples=32, n_importance=32, up_sample_steps=4)
+    args = [t(g[k]) for k in ("rays_o", "rays_d", "near", "far", "depth_scale")]
+    var, bp, gp = torch.tensor([0.3]), torch.tensor([0.5]), torch.tensor([0.3])
+    out = O.render(state, cfg, rcfg, *args, var, bp, gp, cos_anneal_ratio=1.0, flip_saturation=0.9,
+                   t_rand=t(g["t_rand"]))
+    close(out["mid_z_vals"], t(g["mid_z_vals"]), 1e-6, 1e-6)
+    close(out["edge"], t(g["edge"]), 1e-4, 1e-6)
+    # python-float near/far, the way the runner calls render()
+    out_f = O.render(state, cfg, rcfg, args[0], args[1], 0.05, 6.0, args[4], var, bp, gp, cos_anneal_ratio=1.0,
+                     flip_saturation=0.9, t_rand=t(g["t_rand"]))
+    close(out_f["mid_z_vals"], t(g["mid_z_float_nearfar"]), 1e-6, 1e-6)
+    close(out_f["edge"], t(g["edge_float_nearfar"]), 1e-4, 1e-6)
+
+
+def test_g8_scalars():
+    g = load_golden("g8_scalars")
+    close(O.inv_s_from_variance(torch.tensor([0.3])).reshape(1, 1).expand(5, 1), t(g["inv_s"]))
+    close(O.beta_from_param(torch.tensor([0.5])), t(g["beta"]))
+    close(O.gamma_from_param(torch.tensor([0.3])), t(g["gamma"]))
