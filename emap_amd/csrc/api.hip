@@ -1,0 +1,290 @@
+// api.hip - the extern "C" surface of libemap_hip.so (include/emap_hip.h) and the host-side
+// orchestration of one forward render: every kernel of UDFRendererBlending.render
+// (reference src/models/udf_renderer_blending.py:679-800) is enqueued back-to-back on the caller's
+// stream with zero host synchronisation (the reference has >= 11 device->host syncs per render,
+// SURVEY.md par. 3.1).
+#include "emap_common.h"
+#include <stdarg.h>
+#include <string.h>
+#include <algorithm>
+
+namespace emap {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int check_launch(const char* what) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return EMAP_E_LAUNCH;
+    }
+    return EMAP_OK;
+}
+
+int launch_sample_pdf(const float*, const float*, int, int, int, float*, int64_t*, int32_t*, hipStream_t);
+int launch_upsample(const float*, const float*, const float*, const float*, int, int, int, const float*, float, float,
+                    float, float*, int64_t*, int32_t*, hipStream_t);
+int launch_merge(const float*, const float*, const float*, const float*, int, int, int, float*, float*, int64_t*,
+                 hipStream_t);
+int launch_coarse(const float*, const float*, const float*, int, int, float*, float*, hipStream_t);
+int launch_composite(const float*, const float*, const float*, const float*, const float*, const float*, int, int,
+                     const float*, float, float, float, float, int, float, float, float, float, int, const float*,
+                     const float*, const float*, float, const EmapCompositeOut*, float*, int32_t*, hipStream_t);
+int launch_embed(const float*, int64_t, int, float*, hipStream_t);
+void linspace_host(float, float, int, float*);
+
+static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// ---- optional per-launch timing of the dominant kernel (the final value+grad MLP pass) ----------
+// bench.py enables it for the timed region; hipEvents are recorded on the launch stream right
+// before/after that kernel, and read back after the region's final synchronisation.
+constexpr int PROF_MAX = 4096;
+static bool g_prof_on = false;
+static int g_prof_n = 0;
+static hipEvent_t g_prof_ev[PROF_MAX][2];
+static bool g_prof_init = false;
+
+struct Workspace {
+    size_t sample_dist, z_a, z_b, udf_a, udf_b, z_new, udf_new, partials, total;
+};
+
+static Workspace plan_workspace(const EmapRenderParams& p) {
+    const size_t N = (size_t)std::max(p.n_rays, 0);
+    const int m = p.up_sample_steps > 0 ? p.n_importance / p.up_sample_steps : 0;
+    const size_t S = (size_t)p.n_samples + (size_t)m * std::max(p.up_sample_steps, 0);
+    Workspace w;
+    size_t off = 0;
+    w.sample_dist = off; off += 256;
+    w.z_a = off; off += align256(N * S * 4);
+    w.z_b = off; off += align256(N * S * 4);
+    w.udf_a = off; off += align256(N * S * 4);
+    w.udf_b = off; off += align256(N * S * 4);
+    w.z_new = off; off += align256(N * (size_t)std::max(m, 1) * 4);
+    w.udf_new = off; off += align256(N * (size_t)std::max(m, 1) * 4);
+    w.partials = off; off += align256(N * 8 * 4);
+    w.total = off;
+    return w;
+}
+
+}  // namespace emap
+
+using namespace emap;
+
+extern "C" {
+
+int emap_abi_version(void) { return EMAP_ABI_VERSION; }
+const char* emap_last_error(void) { return g_err; }
+
+int emap_packed_bytes(const EmapNetConfig* cfg, int prec, size_t* bytes) {
+    NetLayout L;
+    const int rc = build_layout(cfg, prec, &L);
+    if (rc) return rc;
+    if (!bytes) { set_error("bytes is null"); return EMAP_E_INVALID; }
+    *bytes = layout_bytes(L);
+    return EMAP_OK;
+}
+
+int emap_pack_weights(const EmapNetConfig* cfg, const float* const* g, const float* const* v, const float* const* b,
+                      void* packed, int prec, void* stream) {
+    NetLayout L;
+    const int rc = build_layout(cfg, prec, &L);
+    if (rc) return rc;
+    if (!g || !v || !b || !packed) { set_error("pack_weights: null pointer"); return EMAP_E_INVALID; }
+    for (int l = 0; l < L.n_lin; ++l)
+        if (!g[l] || !v[l] || !b[l]) { set_error("pack_weights: null tensor for layer %d", l); return EMAP_E_INVALID; }
+    return launch_pack(L, g, v, b, packed, static_cast<hipStream_t>(stream));
+}
+
+static int udf_call(const EmapNetConfig* cfg, const void* packed, int prec, const float* x, int64_t P, float* udf,
+                    float* grad3, void* stream) {
+    NetLayout L;
+    const int rc = build_layout(cfg, prec, &L);
+    if (rc) return rc;
+    if (!packed || !udf || (P > 0 && !x)) { set_error("udf_fwd: null pointer"); return EMAP_E_INVALID; }
+    if (P < 0) { set_error("udf_fwd: negative P"); return EMAP_E_INVALID; }
+    if (P == 0) return EMAP_OK;
+    PointSource src;
+    memset(&src, 0, sizeof(src));
+    src.x = x;
+    return launch_mlp(L, packed, prec, src, P, udf, grad3, static_cast<hipStream_t>(stream));
+}
+
+int emap_udf_fwd(const EmapNetConfig* cfg, const void* packed, int prec, const float* x, int64_t P, float* udf,
+                 void* stream) {
+    return udf_call(cfg, packed, prec, x, P, udf, nullptr, stream);
+}
+
+int emap_udf_fwd_grad(const EmapNetConfig* cfg, const void* packed, int prec, const float* x, int64_t P, float* udf,
+                      float* grad3, void* stream) {
+    if (!grad3) { set_error("udf_fwd_grad: grad3 is null"); return EMAP_E_INVALID; }
+    return udf_call(cfg, packed, prec, x, P, udf, grad3, stream);
+}
+
+int emap_embed(const float* x, int64_t P, int multires, float* pe, void* stream) {
+    if (P > 0 && (!x || !pe)) { set_error("embed: null pointer"); return EMAP_E_INVALID; }
+    return launch_embed(x, P, multires, pe, static_cast<hipStream_t>(stream));
+}
+
+int emap_sample_pdf(const float* bins, const float* weights, int N, int n, int m, float* samples, int64_t* inds,
+                    int32_t* err_flags, void* stream) {
+    if (N > 0 && (!bins || !weights || !samples)) { set_error("sample_pdf: null pointer"); return EMAP_E_INVALID; }
+    return launch_sample_pdf(bins, weights, N, n, m, samples, inds, err_flags, static_cast<hipStream_t>(stream));
+}
+
+int emap_upsample_step(const float* rays_o, const float* rays_d, const float* z, const float* udf, int N, int n, int m,
+                       const float* sample_dist_dev, float inv_s, float beta, float gamma, float* z_new, int64_t* inds,
+                       int32_t* err_flags, void* stream) {
+    if (N > 0 && (!rays_o || !rays_d || !z || !udf || !sample_dist_dev || !z_new)) { set_error("upsample_step: null pointer"); return EMAP_E_INVALID; }
+    return launch_upsample(rays_o, rays_d, z, udf, N, n, m, sample_dist_dev, inv_s, beta, gamma, z_new, inds, err_flags,
+                           static_cast<hipStream_t>(stream));
+}
+
+int emap_merge_sorted(const float* z, const float* z_new, const float* udf, const float* udf_new, int N, int n, int m,
+                      float* z_out, float* udf_out, int64_t* perm, void* stream) {
+    if (N > 0 && (!z || !z_new || !z_out)) { set_error("merge_sorted: null pointer"); return EMAP_E_INVALID; }
+    return launch_merge(z, z_new, udf, udf_new, N, n, m, z_out, udf_out, perm, static_cast<hipStream_t>(stream));
+}
+
+int emap_composite_fwd(const float* rays_o, const float* rays_d, const float* z, const float* udf, const float* grad3,
+                       const float* depth_scale, int N, int S, const float* sample_dist_dev, float inv_s, float beta,
+                       float gamma, float cos_anneal_ratio, int has_cos_anneal, float flip_saturation,
+                       float near_surface, float sparse_scale, float background, int has_background,
+                       const EmapCompositeOut* out, float* partials, int32_t* err_flags, void* stream) {
+    if (N > 0 && (!rays_o || !rays_d || !z || !udf || !grad3 || !sample_dist_dev)) { set_error("composite_fwd: null pointer"); return EMAP_E_INVALID; }
+    return launch_composite(rays_o, rays_d, z, udf, grad3, depth_scale, N, S, sample_dist_dev, inv_s, beta, gamma,
+                            cos_anneal_ratio, has_cos_anneal, flip_saturation, near_surface, sparse_scale, background,
+                            has_background, nullptr, nullptr, nullptr, 0.f, out, partials, err_flags,
+                            static_cast<hipStream_t>(stream));
+}
+
+int emap_composite_fwd_p(const float* rays_o, const float* rays_d, const float* z, const float* udf, const float* grad3,
+                         const float* depth_scale, int N, int S, const float* sample_dist_dev, const EmapRenderParams* p,
+                         const EmapCompositeOut* out, float* partials, int32_t* err_flags, void* stream) {
+    if (!p || (N > 0 && (!rays_o || !rays_d || !z || !udf || !grad3 || !sample_dist_dev))) { set_error("composite_fwd_p: null pointer"); return EMAP_E_INVALID; }
+    return launch_composite(rays_o, rays_d, z, udf, grad3, depth_scale, N, S, sample_dist_dev, p->inv_s, p->beta, p->gamma,
+                            p->cos_anneal_ratio, p->has_cos_anneal, p->flip_saturation, p->near_surface, p->sparse_scale,
+                            p->background, p->has_background, p->variance_dev, p->beta_dev, p->gamma_dev, p->beta_min, out,
+                            partials, err_flags, static_cast<hipStream_t>(stream));
+}
+
+int emap_render_workspace_bytes(const EmapRenderParams* p, size_t* bytes) {
+    if (!p || !bytes) { set_error("render_workspace_bytes: null pointer"); return EMAP_E_INVALID; }
+    *bytes = plan_workspace(*p).total;
+    return EMAP_OK;
+}
+
+int emap_render_fwd(const EmapNetConfig* cfg, const void* packed, int prec, const EmapRenderParams* p,
+                    const float* rays_o, const float* rays_d, const float* near, const float* far, const float* t_rand,
+                    const float* depth_scale, float* z_vals, float* udf, float* grad3, const EmapCompositeOut* out,
+                    void* workspace, size_t workspace_bytes, int32_t* err_flags, void* stream) {
+    NetLayout L;
+    int rc = build_layout(cfg, prec, &L);
+    if (rc) return rc;
+    if (!p || !packed || !rays_o || !rays_d || !near || !far || !z_vals || !udf || !grad3 || !out || !workspace) {
+        set_error("render_fwd: null pointer");
+        return EMAP_E_INVALID;
+    }
+    const int N = p->n_rays, Sc = p->n_samples, K = p->up_sample_steps;
+    if (N <= 0) return EMAP_OK;
+    if (Sc < 2 || p->n_importance < 0 || (p->n_importance > 0 && K < 1)) { set_error("render_fwd: bad sampling configuration"); return EMAP_E_INVALID; }
+    const int m = (p->n_importance > 0) ? p->n_importance / K : 0;
+    const int steps = (m > 0) ? K : 0;
+    const int S = Sc + m * steps;
+    if (S > 256) { set_error("render_fwd: %d samples per ray exceed the kernel limit of 256", S); return EMAP_E_INVALID; }
+    const Workspace w = plan_workspace(*p);
+    if (workspace_bytes < w.total) { set_error("render_fwd: workspace %zu < %zu bytes", workspace_bytes, w.total); return EMAP_E_WORKSPACE; }
+    char* ws = static_cast<char*>(workspace);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float* sample_dist = reinterpret_cast<float*>(ws + w.sample_dist);
+    float* zbuf[2] = {reinterpret_cast<float*>(ws + w.z_a), reinterpret_cast<float*>(ws + w.z_b)};
+    float* ubuf[2] = {reinterpret_cast<float*>(ws + w.udf_a), reinterpret_cast<float*>(ws + w.udf_b)};
+    float* z_new = reinterpret_cast<float*>(ws + w.z_new);
+    float* udf_new = reinterpret_cast<float*>(ws + w.udf_new);
+    float* partials = reinterpret_cast<float*>(ws + w.partials);
+
+    // coarse samples (render() :700-720); with no up-sampling they are the final z_vals
+    float* zc = (steps == 0) ? z_vals : zbuf[0];
+    rc = launch_coarse(near, far, t_rand, N, Sc, zc, sample_dist, st);
+    if (rc) return rc;
+
+    if (steps > 0) {
+        // importance_sample (:802-841)
+        PointSource src;
+        memset(&src, 0, sizeof(src));
+        src.rays_o = rays_o; src.rays_d = rays_d; src.z = zc; src.n_per_ray = Sc; src.mid = 0; src.sample_dist = sample_dist;
+        rc = launch_mlp(L, packed, prec, src, (int64_t)N * Sc, ubuf[0], nullptr, st);
+        if (rc) return rc;
+        int cur = 0, n = Sc;
+        for (int i = 0; i < steps; ++i) {
+            const bool last = (i + 1 == steps);
+            const float inv_s = 64.0f * (float)(1 << i);                       // :826
+            const float beta = 64.0f * (float)(1 << (i + 1));                  // :828
+            const float gamma = std::min(std::max(20.0f * (float)(1 << (K - i)), 20.0f), 320.0f);  // :830
+            rc = launch_upsample(rays_o, rays_d, zbuf[cur], ubuf[cur], N, n, m, sample_dist, inv_s, beta, gamma, z_new,
+                                 nullptr, err_flags, st);
+            if (rc) return rc;
+            if (!last) {
+                src.z = z_new; src.n_per_ray = m;
+                rc = launch_mlp(L, packed, prec, src, (int64_t)N * m, udf_new, nullptr, st);
+                if (rc) return rc;
+                rc = launch_merge(zbuf[cur], z_new, ubuf[cur], udf_new, N, n, m, zbuf[cur ^ 1], ubuf[cur ^ 1], nullptr, st);
+            } else {
+                rc = launch_merge(zbuf[cur], z_new, nullptr, nullptr, N, n, m, z_vals, nullptr, nullptr, st);
+            }
+            if (rc) return rc;
+            cur ^= 1;
+            n += m;
+        }
+    }
+
+    // render_core (:418-677): MLP value + grad at the interval mid-points, then compositing
+    PointSource fin;
+    memset(&fin, 0, sizeof(fin));
+    fin.rays_o = rays_o; fin.rays_d = rays_d; fin.z = z_vals; fin.n_per_ray = S; fin.mid = 1; fin.sample_dist = sample_dist;
+    const bool prof = g_prof_on && g_prof_n < PROF_MAX;
+    if (prof) (void)hipEventRecord(g_prof_ev[g_prof_n][0], st);
+    rc = launch_mlp(L, packed, prec, fin, (int64_t)N * S, udf, grad3, st);
+    if (prof) { (void)hipEventRecord(g_prof_ev[g_prof_n][1], st); ++g_prof_n; }
+    if (rc) return rc;
+    return launch_composite(rays_o, rays_d, z_vals, udf, grad3, depth_scale, N, S, sample_dist, p->inv_s, p->beta, p->gamma,
+                            p->cos_anneal_ratio, p->has_cos_anneal, p->flip_saturation, p->near_surface, p->sparse_scale,
+                            p->background, p->has_background, p->variance_dev, p->beta_dev, p->gamma_dev, p->beta_min, out,
+                            partials, err_flags, st);
+}
+
+int emap_profile_enable(int on) {
+    if (on && !g_prof_init) {
+        for (int i = 0; i < PROF_MAX; ++i)
+            for (int k = 0; k < 2; ++k)
+                if (hipEventCreate(&g_prof_ev[i][k]) != hipSuccess) { set_error("hipEventCreate failed"); return EMAP_E_LAUNCH; }
+        g_prof_init = true;
+    }
+    g_prof_on = on != 0;
+    if (on) g_prof_n = 0;
+    return EMAP_OK;
+}
+
+int emap_profile_read(float* total_ms_host, int* launches_host) {
+    if (!total_ms_host || !launches_host) { set_error("profile_read: null pointer"); return EMAP_E_INVALID; }
+    float tot = 0.f;
+    for (int i = 0; i < g_prof_n; ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, g_prof_ev[i][0], g_prof_ev[i][1]) != hipSuccess) { set_error("hipEventElapsedTime failed (region not synchronised?)"); return EMAP_E_LAUNCH; }
+        tot += ms;
+    }
+    *total_ms_host = tot;
+    *launches_host = g_prof_n;
+    return EMAP_OK;
+}
+
+/* host-only helper used by the CPU tests: the u grid of sample_pdf / the coarse z grid */
+void emap_linspace_host(float start, float end, int steps, float* out_host) { linspace_host(start, end, steps, out_host); }
+
+}  // extern "C"

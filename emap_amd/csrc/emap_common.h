@@ -1,0 +1,68 @@
+// emap_common.h - shared host/device definitions for libemap_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/emap_hip.h"
+
+namespace emap {
+
+// ---- error plumbing (host) ------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+// ---- packed-weight layout -------------------------------------------------------------------
+// The MLP kernels keep activations in registers in MFMA-fragment order and never transpose them:
+// the K dimension of layer l+1 is *permuted* so that the 8 k-values lane group g feeds to K-step s
+// are exactly the 8 outputs of layer l it already holds (two 16-feature output tiles 2s, 2s+1, rows
+// 4g..4g+3 of each).  The weights are packed once per optimizer step in the matching order.
+//
+// packed buffer = [bias  n_lin*H f32][rowscale n_lin*H f32][fragments ...]
+// fragment      = one MFMA A operand (16 out-features x 32 k) = 64 lanes x 8 bf16 = 1 KiB,
+//                 lane l=(g<<4)|i holds W[16*tile+i][kmap(s,g,0..7)]
+// fragment order= layer, out-pair p, K-step s (PE block first), tile-in-pair t, part (hi, lo)
+constexpr int FRAG_BYTES = 1024;
+constexpr int PE_KS = 2;          // the PE block always occupies 2 K-steps (64 slots >= 3+6*10)
+
+struct LayerDesc {
+    int32_t pe_ks;      // 2 if the layer's input contains the PE block (layer 0, skip layer)
+    int32_t h_ks;       // H/32 if the layer's input contains the previous hidden layer
+    int32_t n_pairs;    // ceil(out_dim / 32): output tile pairs
+    int32_t out_dim;    // real output features
+    int32_t in_prev;    // real features taken from the previous layer (x part)
+    int32_t frag_off;   // first fragment of the layer (in fragments, parts included)
+    int32_t act;        // 1 = softplus(beta=100) after the layer
+    int32_t pad;
+};
+
+struct NetLayout {
+    int32_t H, n_lin, skip_l, multires, d0, nparts, udf_type, n_chunks;
+    float scale;
+    int32_t total_frags;
+    int32_t bias_off_bytes, rowscale_off_bytes, frag_off_bytes;
+    int32_t pad0;
+    LayerDesc layer[EMAP_MAX_LIN];
+};
+
+// returns 0 or EMAP_E_INVALID (error text set)
+int build_layout(const EmapNetConfig* cfg, int prec, NetLayout* L);
+inline size_t layout_bytes(const NetLayout& L) { return (size_t)L.frag_off_bytes + (size_t)L.total_frags * FRAG_BYTES; }
+
+// launchers implemented in the .hip files
+int launch_pack(const NetLayout& L, const float* const* g, const float* const* v, const float* const* b,
+                void* packed, hipStream_t st);
+
+struct PointSource {
+    const float* x;            // explicit (P,3) points, or nullptr:
+    const float* rays_o;       // (N,3)
+    const float* rays_d;       // (N,3)
+    const float* z;            // (N,n)
+    int32_t n_per_ray;         // n
+    int32_t mid;               // 1: evaluate at z + dists/2 with dists[last] = *sample_dist (render_core :435-449)
+    const float* sample_dist;  // device scalar (mid=1)
+};
+
+int launch_mlp(const NetLayout& L, const void* packed, int prec, const PointSource& src, int64_t P,
+               float* udf, float* grad3, hipStream_t st);
+
+}  // namespace emap

@@ -1,0 +1,517 @@
+// sampler.hip - per-ray kernels of the EMAP renderer for gfx950: coarse z_vals, occlusion-aware
+// up-sampling (up_sample_unbias + sample_pdf), sorted merge (cat_z_vals) and the compositing tail of
+// render_core.  HBM-light, latency-bound work: one 64-lane wavefront per ray, the ray's samples live
+// in LDS, prefix products / sums are wave scans (no torch.cumprod / sort / searchsorted launches, no
+// host synchronisation).
+//
+// Reference behaviour (cvg/EMAP, src/models/udf_renderer_blending.py):
+//   sample_pdf :69-109   up_sample_unbias :228-353   cat_z_vals :355-377   sdf2alpha :379-416
+//   udf2logistic :155-170   render :700-720 (coarse z)   render_core :435-455,463-677
+//
+// Numerics: every elementwise expression is evaluated in fp32 in the reference's operation order
+// with separately rounded mul/add (no fma contraction) so that, given identical fp32 inputs, the
+// integer outputs (searchsorted indices, merge permutation) are bit-exact; scans accumulate in
+// fp64 and round each output to fp32, which is what torch's CPU cumsum/cumprod do
+// (acc_type<float, /*is_cuda=*/false> == double).
+#include "emap_common.h"
+
+namespace emap {
+
+constexpr int MAXS = 256;  // max samples per ray handled by the per-ray kernels
+
+#define FADD(a, b) __fadd_rn((a), (b))
+#define FSUB(a, b) __fsub_rn((a), (b))
+#define FMUL(a, b) __fmul_rn((a), (b))
+#define FDIV(a, b) __fdiv_rn((a), (b))
+
+__device__ __forceinline__ float sigmoidf_(float x) { return FDIV(1.0f, FADD(1.0f, expf(-x))); }
+__device__ __forceinline__ float clipf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+__device__ __forceinline__ float relu_(float x) { return fmaxf(x, 0.0f); }
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// Exclusive prefix product (MUL=true) or inclusive prefix sum (MUL=false) over n <= MAXS values in
+// LDS, fp64 accumulation, fp32 outputs.  Each lane owns a contiguous chunk of C = ceil(n/64) values.
+//   MUL : out[i] = prod_{k<i} in[k]   (cumprod(cat([1, x]))[:-1], udf_renderer_blending.py:308-319)
+//   SUM : out[i] = sum_{k<=i} in[k]   (cumsum, :75)
+template <bool MUL>
+__device__ __forceinline__ void wave_scan(const float* in, float* out, int n, int lane) {
+    const int C = (n + 63) >> 6;
+    const int b = lane * C;
+    double loc = MUL ? 1.0 : 0.0;
+    for (int i = 0; i < C; ++i) {
+        const int e = b + i;
+        if (e < n) loc = MUL ? loc * (double)in[e] : loc + (double)in[e];
+    }
+    // exclusive scan of the chunk totals across lanes (Kogge-Stone)
+    double inc = loc;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double o = __shfl_up(inc, off);
+        if (lane >= off) inc = MUL ? inc * o : inc + o;
+    }
+    double pre = __shfl_up(inc, 1);
+    if (lane == 0) pre = MUL ? 1.0 : 0.0;
+    double run = pre;
+    for (int i = 0; i < C; ++i) {
+        const int e = b + i;
+        if (e < n) {
+            if (MUL) {
+                out[e] = (float)run;
+                run *= (double)in[e];
+            } else {
+                run += (double)in[e];
+                out[e] = (float)run;
+            }
+        }
+    }
+}
+
+// torch.linspace(start, end, steps)[i] for fp32 (ATen RangeFactories: step = (end-start)/(steps-1),
+// first half counted up from start, second half counted down from end).
+__device__ __forceinline__ float linspace_at(float start, float end, int steps, int i) {
+    if (steps == 1) return start;
+    const float step = FDIV(FSUB(end, start), (float)(steps - 1));
+    return (i < steps / 2) ? FADD(start, FMUL(step, (float)i)) : FSUB(end, FMUL(step, (float)(steps - i - 1)));
+}
+static float linspace_at_host(float start, float end, int steps, int i) {
+    if (steps == 1) return start;
+    volatile float step = (end - start) / (float)(steps - 1);
+    volatile float a = step * (float)i;
+    volatile float b = step * (float)(steps - i - 1);
+    return (i < steps / 2) ? start + a : end - b;
+}
+
+// sdf2alpha, 'numerical' branch (udf_renderer_blending.py:379-411)
+__device__ __forceinline__ float sdf2alpha(float sdf, float true_cos, float dists, float inv_s, bool anneal, float car) {
+    float iter_cos = true_cos;
+    if (anneal) {
+        const float a = FMUL(relu_(FADD(FMUL(-true_cos, 0.5f), 0.5f)), FSUB(1.0f, car));
+        const float b = FMUL(relu_(-true_cos), car);
+        iter_cos = -FADD(a, b);
+    }
+    const float h = FMUL(FMUL(iter_cos, dists), 0.5f);
+    const float est_next = FADD(sdf, h);
+    const float est_prev = FSUB(sdf, h);
+    const float prev_cdf = sigmoidf_(FMUL(est_prev, inv_s));
+    const float next_cdf = sigmoidf_(FMUL(est_next, inv_s));
+    const float p = FSUB(prev_cdf, next_cdf);
+    return clipf(FDIV(FADD(p, 1e-5f), FADD(prev_cdf, 1e-5f)), 0.0f, 1.0f);
+}
+
+// udf2logistic(udf, inv_s, gamma=1, abs_cos=1) (udf_renderer_blending.py:155-170)
+__device__ __forceinline__ float udf2logistic1(float udf, float inv_s) {
+    const float e = expf(FMUL(-inv_s, udf));
+    const float den = FADD(1.0f, e);
+    return FDIV(FMUL(inv_s, e), FMUL(den, den));
+}
+
+// ---------------------------------------------------------------------------------------------
+// sample_pdf on LDS data (bins[n], w[n-1] raw weights; scratch pdf[n], cdf[n])
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void sample_pdf_wave(const float* bins, const float* w, float* pdf, float* cdf, int n, int m,
+                                                int lane, float* samples_out, int64_t* inds_out, int32_t* err) {
+    const int nw = n - 1;
+    double part = 0.0;
+    for (int e = lane; e < nw; e += 64) {
+        const float we = FADD(w[e], 1e-5f);
+        pdf[e] = we;
+        part += (double)we;
+    }
+    const float total = (float)wave_sum_d(part);
+    for (int e = lane; e < nw; e += 64) pdf[e] = FDIV(pdf[e], total);
+    wave_scan<false>(pdf, cdf + 1, nw, lane);
+    if (lane == 0) cdf[0] = 0.0f;
+    const float u0 = (float)(0.0 + 0.5 / (double)m), u1 = (float)(1.0 - 0.5 / (double)m);
+    bool nan = false;
+    for (int k = lane; k < m; k += 64) {
+        const float u = linspace_at(u0, u1, m, k);
+        // searchsorted(cdf, u, right=True): first index with cdf[idx] > u
+        int lo = 0, hi = n;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (cdf[mid] <= u) lo = mid + 1; else hi = mid;
+        }
+        const int ind = lo;
+        const int below = max(ind - 1, 0), above = min(n - 1, ind);
+        const float cb = cdf[below], ca = cdf[above], bb = bins[below], ba = bins[above];
+        float denom = FSUB(ca, cb);
+        if (denom < 1e-5f) denom = 1.0f;
+        const float t = FDIV(FSUB(u, cb), denom);
+        const float s = FADD(bb, FMUL(t, FSUB(ba, bb)));
+        samples_out[k] = s;
+        if (inds_out) inds_out[k] = ind;
+        nan |= (s != s);
+    }
+    if (err && __any(nan)) { if (lane == 0) atomicOr(err, EMAP_F_NAN_SAMPLES); }
+}
+
+__global__ __launch_bounds__(64) void sample_pdf_kernel(const float* bins, const float* weights, int N, int n, int m,
+                                                        float* samples, int64_t* inds, int32_t* err) {
+    __shared__ float s_bins[MAXS], s_w[MAXS], s_pdf[MAXS], s_cdf[MAXS + 1];
+    const int ray = blockIdx.x, lane = threadIdx.x;
+    for (int e = lane; e < n; e += 64) s_bins[e] = bins[(size_t)ray * n + e];
+    for (int e = lane; e < n - 1; e += 64) s_w[e] = weights[(size_t)ray * (n - 1) + e];
+    __syncthreads();
+    sample_pdf_wave(s_bins, s_w, s_pdf, s_cdf, n, m, lane, samples + (size_t)ray * m, inds ? inds + (size_t)ray * m : nullptr, err);
+}
+
+// ---------------------------------------------------------------------------------------------
+// up_sample_unbias (udf_renderer_blending.py:228-353) -> z_new (N,m)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void upsample_kernel(const float* rays_o, const float* rays_d, const float* z,
+                                                      const float* udf, int N, int n, int m, const float* sample_dist,
+                                                      float inv_s, float beta, float gamma, float* z_new, int64_t* inds,
+                                                      int32_t* err) {
+    __shared__ float s_z[MAXS], s_u[MAXS], s_rad[MAXS], s_tc[MAXS], s_a[MAXS], s_b[MAXS], s_c[MAXS], s_d[MAXS + 1];
+    const int ray = blockIdx.x, lane = threadIdx.x;
+    const float ox = rays_o[3 * ray], oy = rays_o[3 * ray + 1], oz = rays_o[3 * ray + 2];
+    const float dx = rays_d[3 * ray], dy = rays_d[3 * ray + 1], dz = rays_d[3 * ray + 2];
+    const float sd = *sample_dist;
+    for (int e = lane; e < n; e += 64) {
+        const float zz = z[(size_t)ray * n + e];
+        s_z[e] = zz;
+        s_u[e] = udf[(size_t)ray * n + e];
+        const float px = FADD(ox, FMUL(dx, zz)), py = FADD(oy, FMUL(dy, zz)), pz = FADD(oz, FMUL(dz, zz));
+        s_rad[e] = sqrtf(FADD(FADD(FMUL(px, px), FMUL(py, py)), FMUL(pz, pz)));  // :249
+    }
+    __syncthreads();
+    // true_cos over intervals (:279) and vis_prob input over samples (:293-313)
+    for (int e = lane; e < n - 1; e += 64)
+        s_tc[e] = FDIV(FSUB(s_u[e + 1], s_u[e]), FADD(FSUB(s_z[e + 1], s_z[e]), 1e-5f));
+    __syncthreads();
+    for (int e = lane; e < n; e += 64) {
+        const float dists_raw = (e < n - 1) ? FSUB(s_z[e + 1], s_z[e]) : sd;           // :254-263
+        const float vis_mask = (e == 0) ? 1.0f : ((s_tc[e - 1] < 0.05f) ? 1.0f : 0.0f);  // :293-300
+        const float raw_occ = udf2logistic1(s_u[e], beta);                               // :303
+        const float alpha_occ = FSUB(1.0f, expf(FMUL(FMUL(-relu_(raw_occ), gamma), dists_raw)));  // :305
+        s_a[e] = FADD(clipf(FADD(FSUB(1.0f, alpha_occ), vis_mask), 0.0f, 1.0f), 1e-7f);  // :312
+    }
+    __syncthreads();
+    wave_scan<true>(s_a, s_b, n, lane);  // vis_prob (:308-319)
+    __syncthreads();
+    for (int e = lane; e < n - 1; e += 64) {
+        const float cv = -fabsf(s_tc[e]);
+        const float pcv = (e == 0) ? 0.0f : -fabsf(s_tc[e - 1]);
+        const bool inside = (s_rad[e] < 1.0f) | (s_rad[e + 1] < 1.0f);                   // :250
+        float cos_val = clipf(fminf(pcv, cv), -1e3f, 0.0f);                              // :284-290
+        cos_val = inside ? cos_val : FMUL(cos_val, 0.0f);
+        const float mid_udf = FMUL(FADD(s_u[e], s_u[e + 1]), 0.5f);
+        const float dists = FSUB(s_z[e + 1], s_z[e]);
+        const float ap = sdf2alpha(mid_udf, cos_val, dists, inv_s, false, 0.f);          // :327-330
+        const float am = sdf2alpha(-mid_udf, cos_val, dists, inv_s, false, 0.f);
+        const float sp = s_b[e];
+        const float alpha = FADD(FMUL(ap, sp), FMUL(am, FSUB(1.0f, sp)));               // :331
+        s_c[e] = alpha;
+        s_a[e] = FADD(FSUB(1.0f, alpha), 1e-7f);
+    }
+    __syncthreads();
+    wave_scan<true>(s_a, s_b, n - 1, lane);  // transmittance (:334-343)
+    __syncthreads();
+    for (int e = lane; e < n - 1; e += 64) s_c[e] = FMUL(s_c[e], s_b[e]);  // weights
+    __syncthreads();
+    sample_pdf_wave(s_z, s_c, s_a, s_d, n, m, lane, z_new + (size_t)ray * m, inds ? inds + (size_t)ray * m : nullptr, err);
+}
+
+// ---------------------------------------------------------------------------------------------
+// cat_z_vals: merge two sorted lists (stable: old samples first on ties), gather udf
+// (udf_renderer_blending.py:361-375)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void merge_kernel(const float* z, const float* z_new, const float* udf,
+                                                   const float* udf_new, int N, int n, int m, float* z_out,
+                                                   float* udf_out, int64_t* perm) {
+    __shared__ float s_z[MAXS], s_n[MAXS];
+    const int ray = blockIdx.x, lane = threadIdx.x;
+    for (int e = lane; e < n; e += 64) s_z[e] = z[(size_t)ray * n + e];
+    for (int e = lane; e < m; e += 64) s_n[e] = z_new[(size_t)ray * m + e];
+    __syncthreads();
+    const size_t ob = (size_t)ray * (n + m);
+    for (int e = lane; e < n + m; e += 64) {
+        int rank;
+        float v;
+        if (e < n) {
+            v = s_z[e];
+            int lo = 0, hi = m;  // # new elements strictly less than v
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_n[mid] < v) lo = mid + 1; else hi = mid; }
+            rank = e + lo;
+        } else {
+            v = s_n[e - n];
+            int lo = 0, hi = n;  // # old elements <= v
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_z[mid] <= v) lo = mid + 1; else hi = mid; }
+            rank = (e - n) + lo;
+        }
+        z_out[ob + rank] = v;
+        if (perm) perm[ob + rank] = e;
+        if (udf_out) udf_out[ob + rank] = (e < n) ? udf[(size_t)ray * n + e] : udf_new[(size_t)ray * m + (e - n)];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// coarse z_vals + sample_dist (render() :700-720)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void coarse_z_kernel(const float* near, const float* far, const float* t_rand, int N,
+                                                       int n_samples, float* z, float* sample_dist) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < (long long)N * n_samples) {
+        const int ray = (int)(i / n_samples), k = (int)(i - (long long)ray * n_samples);
+        const float lin = linspace_at(0.0f, 1.0f, n_samples, k);
+        float v = FADD(near[ray], FMUL(FSUB(far[ray], near[ray]), lin));                           // :707
+        if (t_rand) v = FADD(v, FDIV(FMUL(t_rand[ray], 2.0f), (float)n_samples));                  // :720
+        z[i] = v;
+    }
+    if (blockIdx.x == 0) {  // sample_dist = ((far - near) / n_samples).mean()                          :704
+        __shared__ double red[4];
+        double s = 0.0;
+        for (int r = threadIdx.x; r < N; r += 256) s += (double)FDIV(FSUB(far[r], near[r]), (float)n_samples);
+        s = wave_sum_d(s);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) *sample_dist = (float)((red[0] + red[1] + red[2] + red[3]) / (double)N);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// render_core tail (udf_renderer_blending.py:435-455,463-677)
+// ---------------------------------------------------------------------------------------------
+struct CompositeArgs {
+    const float *rays_o, *rays_d, *z, *udf, *grad, *depth_scale, *sample_dist;
+    int N, S;
+    float inv_s, beta, gamma, car;
+    int anneal;
+    float flip_sat, near_surface, sparse_scale, background;
+    int has_bg;
+    const float *var_p, *beta_p, *gamma_p;  // optional raw device parameters (see EmapRenderParams)
+    float beta_min;
+    EmapCompositeOut out;
+    float* partials;
+};
+
+__global__ __launch_bounds__(64) void composite_kernel(const CompositeArgs a) {
+    __shared__ float s_z[MAXS], s_tc[MAXS], s_a[MAXS], s_b[MAXS], s_al[MAXS], s_occ[MAXS];
+    const int ray = blockIdx.x, lane = threadIdx.x, S = a.S;
+    const float ox = a.rays_o[3 * ray], oy = a.rays_o[3 * ray + 1], oz = a.rays_o[3 * ray + 2];
+    const float dx = a.rays_d[3 * ray], dy = a.rays_d[3 * ray + 1], dz = a.rays_d[3 * ray + 2];
+    const float sd = *a.sample_dist;
+    float inv_s_ = a.inv_s, beta_ = a.beta, gamma_ = a.gamma;
+    if (a.var_p) {  // udf_model.py:226-227,259-263 + udf_renderer_blending.py:466-472
+        inv_s_ = clipf(expf(FMUL(a.var_p[0], 10.0f)), 1e-6f, 1e6f);
+        beta_ = clipf(clipf(expf(FMUL(a.beta_p[0], 10.0f)), 0.0f, FDIV(1.0f, a.beta_min)), 1e-6f, 1e6f);
+        gamma_ = clipf(expf(FMUL(a.gamma_p[0], 10.0f)), 1e-6f, 1e6f);
+    }
+    const size_t rb = (size_t)ray * S;
+    for (int e = lane; e < S; e += 64) s_z[e] = a.z[rb + e];
+    __syncthreads();
+    // pass 1: true_cos and alpha_occ
+    for (int e = lane; e < S; e += 64) {
+        const float gx = a.grad[3 * (rb + e)], gy = a.grad[3 * (rb + e) + 1], gz = a.grad[3 * (rb + e) + 2];
+        s_tc[e] = FADD(FADD(FMUL(dx, gx), FMUL(dy, gy)), FMUL(dz, gz));                 // :482
+        const float dists = (e < S - 1) ? FSUB(s_z[e + 1], s_z[e]) : sd;                // :435-444
+        const float raw_occ = udf2logistic1(a.udf[rb + e], beta_);                      // :492
+        s_occ[e] = FSUB(1.0f, expf(FMUL(FMUL(-relu_(raw_occ), gamma_), dists)));        // :497
+    }
+    __syncthreads();
+    for (int e = lane; e < S; e += 64) {
+        const float vis_mask = (e < S - 1) ? ((s_tc[e + 1] < 0.01f) ? 1.0f : 0.0f) : 1.0f;  // :500-509
+        s_a[e] = FADD(clipf(FADD(FSUB(1.0f, s_occ[e]), FMUL(a.flip_sat, vis_mask)), 0.0f, 1.0f), 1e-7f);  // :515
+    }
+    __syncthreads();
+    wave_scan<true>(s_a, s_b, S, lane);  // vis_prob (:511-523)
+    __syncthreads();
+    for (int e = lane; e < S; e += 64) {
+        const float vp = clipf(s_b[e], 0.0f, 1.0f);                                     // :528
+        const float dists = (e < S - 1) ? FSUB(s_z[e + 1], s_z[e]) : sd;
+        const float u = a.udf[rb + e];
+        const float tc = -fabsf(s_tc[e]);
+        const float ap = sdf2alpha(u, tc, dists, inv_s_, a.anneal != 0, a.car);         // :530-543
+        const float am = sdf2alpha(-u, tc, dists, inv_s_, a.anneal != 0, a.car);
+        const float alpha = FADD(FMUL(ap, vp), FMUL(am, FSUB(1.0f, vp)));               // :545
+        s_al[e] = alpha;
+        s_a[e] = FADD(FSUB(1.0f, alpha), 1e-7f);
+    }
+    __syncthreads();
+    wave_scan<true>(s_a, s_b, S, lane);  // transmittance (:593-602)
+    __syncthreads();
+    double wsum = 0, dsum = 0, nx = 0, ny = 0, nz = 0, e_rel = 0, c_rel = 0, e_ns = 0, c_ns = 0, sp = 0;
+    for (int e = lane; e < S; e += 64) {
+        const float alpha = s_al[e];
+        const float w = FMUL(alpha, s_b[e]);
+        const float dists = (e < S - 1) ? FSUB(s_z[e + 1], s_z[e]) : sd;
+        const float mid = FADD(s_z[e], FMUL(dists, 0.5f));                              // :446
+        const float px = FADD(ox, FMUL(dx, mid)), py = FADD(oy, FMUL(dy, mid)), pz = FADD(oz, FMUL(dz, mid));
+        const float pn = sqrtf(FADD(FADD(FMUL(px, px), FMUL(py, py)), FMUL(pz, pz)));   // :563
+        const float gx = a.grad[3 * (rb + e)], gy = a.grad[3 * (rb + e) + 1], gz = a.grad[3 * (rb + e) + 2];
+        const float gm = sqrtf(FADD(FADD(FMUL(gx, gx), FMUL(gy, gy)), FMUL(gz, gz)));   // :463
+        const float gi = FADD(gm, 1e-5f);
+        const float cosn = FADD(FADD(FMUL(dx, FDIV(gx, gi)), FMUL(dy, FDIV(gy, gi))), FMUL(dz, FDIV(gz, gi)));  // :485
+        float flip = (cosn > 0.f) ? -1.0f : ((cosn < 0.f) ? 1.0f : 1.0f);               // :486-489
+        const float u = a.udf[rb + e];
+        const float inside = (pn < 2.0f) ? 1.0f : 0.0f, relax = (pn < 2.4f) ? 1.0f : 0.0f;  // :568-569
+        const float ns = (u < a.near_surface) ? 1.0f : 0.0f;                            // :570
+        const float ge = FMUL(FSUB(gm, 1.0f), FSUB(gm, 1.0f));                          // :612-617
+        if (a.out.weights) a.out.weights[rb + e] = w;
+        if (a.out.alpha) a.out.alpha[rb + e] = alpha;
+        if (a.out.mid_z) a.out.mid_z[rb + e] = mid;
+        if (a.out.dists) a.out.dists[rb + e] = dists;
+        if (a.out.inside_sphere) a.out.inside_sphere[rb + e] = inside;
+        if (a.out.gradient_mag) a.out.gradient_mag[rb + e] = gm;
+        if (a.out.gradients_flip) {
+            a.out.gradients_flip[3 * (rb + e)] = FMUL(flip, gx);
+            a.out.gradients_flip[3 * (rb + e) + 1] = FMUL(flip, gy);
+            a.out.gradients_flip[3 * (rb + e) + 2] = FMUL(flip, gz);
+        }
+        wsum += w;
+        dsum += (double)FMUL(mid, w);
+        nx += (double)FMUL(FMUL(flip, gx), w); ny += (double)FMUL(FMUL(flip, gy), w); nz += (double)FMUL(FMUL(flip, gz), w);
+        e_rel += (double)FMUL(relax, ge); c_rel += relax;
+        e_ns += (double)FMUL(ns, ge); c_ns += ns;
+        sp += (double)expf(FMUL(-a.sparse_scale, u));                                   // :642-644
+    }
+    wsum = wave_sum_d(wsum); dsum = wave_sum_d(dsum);
+    nx = wave_sum_d(nx); ny = wave_sum_d(ny); nz = wave_sum_d(nz);
+    e_rel = wave_sum_d(e_rel); c_rel = wave_sum_d(c_rel); e_ns = wave_sum_d(e_ns); c_ns = wave_sum_d(c_ns);
+    sp = wave_sum_d(sp);
+    if (lane == 0) {
+        const float ws = (float)wsum;
+        float edge = ws;                                                                 // :606 (sampled_edge == 1)
+        if (a.has_bg) edge = FADD(edge, FMUL(a.background, FSUB(1.0f, ws)));             // :608-609
+        if (a.out.edge) a.out.edge[ray] = edge;
+        if (a.out.weight_sum) a.out.weight_sum[ray] = ws;
+        if (a.out.depth) a.out.depth[ray] = a.depth_scale ? FMUL((float)dsum, a.depth_scale[ray]) : (float)dsum;  // :607, render :786
+        if (a.out.normals) { a.out.normals[3 * ray] = (float)nx; a.out.normals[3 * ray + 1] = (float)ny; a.out.normals[3 * ray + 2] = (float)nz; }
+        float* p = a.partials + (size_t)ray * 8;
+        p[0] = (float)e_rel; p[1] = (float)c_rel; p[2] = (float)e_ns; p[3] = (float)c_ns; p[4] = (float)sp;
+    }
+}
+
+// deterministic cross-ray reduction of the eikonal terms (:618-625) and sparse_error (:642-644)
+__global__ __launch_bounds__(256) void composite_reduce_kernel(const float* partials, int N, float* scalars, int32_t* err,
+                                                               const CompositeArgs a) {
+    __shared__ double red[4][5];
+    double v[5] = {0, 0, 0, 0, 0};
+    for (int i = threadIdx.x; i < N; i += 256)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) v[k] += (double)partials[(size_t)i * 8 + k];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) v[k] = wave_sum_d(v[k]);
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) red[threadIdx.x >> 6][k] = v[k];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t[5];
+        for (int k = 0; k < 5; ++k) t[k] = red[0][k] + red[1][k] + red[2][k] + red[3][k];
+        const float e_rel = (float)t[0], c_rel = (float)t[1], e_ns = (float)t[2], c_ns = (float)t[3];
+        const float ge = FDIV(e_rel, FADD(c_rel, 1e-5f));
+        scalars[0] = ge;
+        scalars[1] = FDIV(e_ns, FADD(c_ns, 1e-5f));
+        scalars[2] = (float)(t[4] / (double)N);
+        scalars[3] = e_rel; scalars[4] = c_rel; scalars[5] = e_ns; scalars[6] = c_ns; scalars[7] = (float)t[4];
+        // s_val = 1/inv_s, 1/beta, gamma: the "variance"/"beta"/"gamma" entries of the render dict (:656-658)
+        float inv_s_ = a.inv_s, beta_ = a.beta, gamma_ = a.gamma;
+        if (a.var_p) {
+            inv_s_ = clipf(expf(FMUL(a.var_p[0], 10.0f)), 1e-6f, 1e6f);
+            beta_ = clipf(clipf(expf(FMUL(a.beta_p[0], 10.0f)), 0.0f, FDIV(1.0f, a.beta_min)), 1e-6f, 1e6f);
+            gamma_ = clipf(expf(FMUL(a.gamma_p[0], 10.0f)), 1e-6f, 1e6f);
+        }
+        scalars[8] = FDIV(1.0f, inv_s_); scalars[9] = FDIV(1.0f, beta_); scalars[10] = gamma_; scalars[11] = inv_s_;
+        if (err && ge != ge) atomicOr(err, EMAP_F_NAN_GRADERR);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Embedder.embed (embedder.py:34-35): x (P,3) -> (P, 3+6L), reference column order
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_kernel(const float* x, long long P, int L, float* pe) {
+    const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    const int d0 = 3 + 6 * L;
+    const float xs[3] = {x[3 * p], x[3 * p + 1], x[3 * p + 2]};
+    float* o = pe + p * d0;
+    o[0] = xs[0]; o[1] = xs[1]; o[2] = xs[2];
+    for (int k = 0; k < L; ++k) {
+        const float f = (float)(1 << k);
+        for (int c = 0; c < 3; ++c) {
+            float sn, cs;
+            sincosf(FMUL(xs[c], f), &sn, &cs);
+            o[3 + 6 * k + c] = sn;
+            o[3 + 6 * k + 3 + c] = cs;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+int launch_sample_pdf(const float* bins, const float* weights, int N, int n, int m, float* samples, int64_t* inds,
+                      int32_t* err, hipStream_t st) {
+    if (n < 2 || n > MAXS || m < 1 || m > MAXS) { set_error("sample_pdf: n=%d m=%d out of range (max %d)", n, m, MAXS); return EMAP_E_INVALID; }
+    if (N <= 0) return EMAP_OK;
+    hipLaunchKernelGGL(sample_pdf_kernel, dim3(N), dim3(64), 0, st, bins, weights, N, n, m, samples, inds, err);
+    return check_launch("sample_pdf");
+}
+
+int launch_upsample(const float* rays_o, const float* rays_d, const float* z, const float* udf, int N, int n, int m,
+                    const float* sample_dist, float inv_s, float beta, float gamma, float* z_new, int64_t* inds,
+                    int32_t* err, hipStream_t st) {
+    if (n < 2 || n > MAXS || m < 1 || m > MAXS) { set_error("upsample_step: n=%d m=%d out of range (max %d)", n, m, MAXS); return EMAP_E_INVALID; }
+    if (N <= 0) return EMAP_OK;
+    hipLaunchKernelGGL(upsample_kernel, dim3(N), dim3(64), 0, st, rays_o, rays_d, z, udf, N, n, m, sample_dist, inv_s, beta,
+                       gamma, z_new, inds, err);
+    return check_launch("upsample_step");
+}
+
+int launch_merge(const float* z, const float* z_new, const float* udf, const float* udf_new, int N, int n, int m,
+                 float* z_out, float* udf_out, int64_t* perm, hipStream_t st) {
+    if (n < 1 || n > MAXS || m < 1 || m > MAXS) { set_error("merge_sorted: n=%d m=%d out of range (max %d)", n, m, MAXS); return EMAP_E_INVALID; }
+    if (udf_out && (!udf || !udf_new)) { set_error("merge_sorted: udf_out needs udf and udf_new"); return EMAP_E_INVALID; }
+    if (N <= 0) return EMAP_OK;
+    hipLaunchKernelGGL(merge_kernel, dim3(N), dim3(64), 0, st, z, z_new, udf, udf_new, N, n, m, z_out, udf_out, perm);
+    return check_launch("merge_sorted");
+}
+
+int launch_coarse(const float* near, const float* far, const float* t_rand, int N, int n_samples, float* z,
+                  float* sample_dist, hipStream_t st) {
+    if (N <= 0) return EMAP_OK;
+    const long long tot = (long long)N * n_samples;
+    hipLaunchKernelGGL(coarse_z_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, near, far, t_rand, N, n_samples, z,
+                       sample_dist);
+    return check_launch("coarse_z");
+}
+
+int launch_composite(const float* rays_o, const float* rays_d, const float* z, const float* udf, const float* grad3,
+                     const float* depth_scale, int N, int S, const float* sample_dist, float inv_s, float beta,
+                     float gamma, float car, int anneal, float flip_sat, float near_surface, float sparse_scale,
+                     float background, int has_bg, const float* var_p, const float* beta_p, const float* gamma_p,
+                     float beta_min, const EmapCompositeOut* out, float* partials, int32_t* err, hipStream_t st) {
+    if (S < 1 || S > MAXS) { set_error("composite: S=%d out of range (max %d)", S, MAXS); return EMAP_E_INVALID; }
+    if (!out || !partials) { set_error("composite: out/partials must not be null"); return EMAP_E_INVALID; }
+    if (N <= 0) return EMAP_OK;
+    CompositeArgs a;
+    a.rays_o = rays_o; a.rays_d = rays_d; a.z = z; a.udf = udf; a.grad = grad3; a.depth_scale = depth_scale;
+    a.sample_dist = sample_dist; a.N = N; a.S = S; a.inv_s = inv_s; a.beta = beta; a.gamma = gamma; a.car = car;
+    a.anneal = anneal; a.flip_sat = flip_sat; a.near_surface = near_surface; a.sparse_scale = sparse_scale;
+    a.background = background; a.has_bg = has_bg; a.out = *out; a.partials = partials;
+    a.var_p = var_p; a.beta_p = beta_p; a.gamma_p = gamma_p; a.beta_min = beta_min;
+    if (var_p && (!beta_p || !gamma_p)) { set_error("composite: variance_dev given without beta_dev/gamma_dev"); return EMAP_E_INVALID; }
+    hipLaunchKernelGGL(composite_kernel, dim3(N), dim3(64), 0, st, a);
+    if (out->scalars) hipLaunchKernelGGL(composite_reduce_kernel, dim3(1), dim3(256), 0, st, partials, N, out->scalars, err, a);
+    return check_launch("composite");
+}
+
+int launch_embed(const float* x, int64_t P, int L, float* pe, hipStream_t st) {
+    if (L < 1 || L > 16) { set_error("embed: multires=%d out of range", L); return EMAP_E_INVALID; }
+    if (P <= 0) return EMAP_OK;
+    hipLaunchKernelGGL(embed_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, x, (long long)P, L, pe);
+    return check_launch("embed");
+}
+
+// host copy of the u grid used by sample_pdf, for CPU-side tests of the linspace restatement
+void linspace_host(float start, float end, int steps, float* out) {
+    for (int i = 0; i < steps; ++i) out[i] = linspace_at_host(start, end, steps, i);
+}
+
+}  // namespace emap

@@ -1,0 +1,276 @@
+"""Fields with the reference interface (reference src/models/udf_model.py), evaluated by libemap_hip.
+
+``UDFNetwork``, ``SingleVarianceNetwork``, ``BetaNetwork`` and ``RenderingNetwork`` keep the
+reference's constructor signatures, parameter names/order (so ``state_dict`` keys and the runner's Adam
+param groups are unchanged: ``lin{l}.bias``, ``lin{l}.parametrizations.weight.original0/1``,
+``variance``, ``second_variance``, ``beta``, ``gamma``, ``zeta``) and method signatures.
+
+What differs is *how* ``forward`` / ``udf`` / ``gradient`` are evaluated: one fused HIP kernel
+(positional encoding + all Linear/Softplus layers [+ forward-mode spatial gradient]) reading a packed
+copy of the weight-normed weights that is rebuilt only when a parameter changes.
+
+Autograd: parameter/input gradients (training) go through ``emap_amd._interim_backward`` - a
+PyTorch-ROCm recomputation on the GPU, the interim stated in SURVEY.md par. 8(f1) until the
+``udf_mlp_vjp`` kernels land.  Inference calls (``torch.no_grad()`` or nothing requiring grad) are
+pure HIP.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .embedder import get_embedder, embed_torch
+
+DEFAULT_PRECISION = os.environ.get("EMAP_PRECISION", "bf16x3")
+
+
+class UDFNetwork(nn.Module):
+    """Reference: src/models/udf_model.py:7-135."""
+
+    def __init__(self, d_in, d_out, d_hidden, n_layers, skip_in=(4,), multires=0, scale=1, bias=0.5,
+                 geometric_init=True, weight_norm=True, udf_type="abs", precision=None):
+        super().__init__()
+        dims = [d_in] + [d_hidden for _ in range(n_layers)] + [d_out]
+        self.embed_fn_fine = None
+        if multires > 0:
+            embed_fn, input_ch = get_embedder(multires, input_dims=d_in)
+            self.embed_fn_fine = embed_fn
+            dims[0] = input_ch
+        self.num_layers = len(dims)
+        self.skip_in = tuple(skip_in)
+        self.scale = scale
+        self.geometric_init = geometric_init
+        self.multires = multires
+        self.d_in, self.d_out, self.d_hidden = d_in, d_out, d_hidden
+        self.weight_norm = weight_norm
+        self.udf_type = udf_type
+        self.precision = precision or DEFAULT_PRECISION
+
+        # same construction and init-call order as udf_model.py:39-76, so a seeded reference run and a
+        # seeded emap_amd run start from identical parameters
+        for l in range(self.num_layers - 1):
+            out_dim = dims[l + 1] - dims[0] if (l + 1) in self.skip_in else dims[l + 1]
+            lin = nn.Linear(dims[l], out_dim)
+            if geometric_init:
+                if l == self.num_layers - 2:
+                    nn.init.normal_(lin.weight, mean=np.sqrt(np.pi) / np.sqrt(dims[l]), std=0.0001)
+                    nn.init.constant_(lin.bias, -bias)
+                elif multires > 0 and l == 0:
+                    nn.init.constant_(lin.bias, 0.0)
+                    nn.init.constant_(lin.weight[:, 3:], 0.0)
+                    nn.init.normal_(lin.weight[:, :3], 0.0, np.sqrt(2) / np.sqrt(out_dim))
+                elif multires > 0 and l in self.skip_in:
+                    nn.init.constant_(lin.bias, 0.0)
+                    nn.init.normal_(lin.weight, 0.0, np.sqrt(2) / np.sqrt(out_dim))
+                    nn.init.constant_(lin.weight[:, -(dims[0] - 3):], 0.0)
+                else:
+                    nn.init.constant_(lin.bias, 0.0)
+                    nn.init.normal_(lin.weight, 0.0, np.sqrt(2) / np.sqrt(out_dim))
+            if weight_norm:
+                lin = nn.utils.parametrizations.weight_norm(lin)
+            setattr(self, "lin" + str(l), lin)
+
+        self.activation = nn.Softplus(beta=100)
+        self.relu = nn.ReLU()
+        self._pack_cache = {}
+
+    # ---- packed weights -----------------------------------------------------------------------
+    def _gvb(self):
+        """(g, v, b) per layer; without weight_norm g = ||v|| so that g*v/||v|| = v."""
+        gs, vs, bs = [], [], []
+        for l in range(self.num_layers - 1):
+            lin = getattr(self, "lin" + str(l))
+            if self.weight_norm:
+                g = lin.parametrizations.weight.original0
+                v = lin.parametrizations.weight.original1
+            else:
+                v = lin.weight
+                g = torch.linalg.norm(v.detach(), dim=1, keepdim=True)
+            gs.append(g); vs.append(v); bs.append(lin.bias)
+        return gs, vs, bs
+
+    def net_config(self) -> _lib.NetConfig:
+        if self.d_in != 3 or self.multires <= 0:
+            raise NotImplementedError("the HIP UDF MLP needs d_in=3 and multires>0 (all EMAP configs)")
+        if self.d_out != 1:
+            raise NotImplementedError("the HIP UDF MLP supports d_out=1 (all EMAP configs); feature outputs are unused")
+        skips = [s for s in self.skip_in if 0 < s < self.num_layers - 1]
+        if len(skips) > 1:
+            raise NotImplementedError("at most one skip connection is supported")
+        return _lib.NetConfig(self.d_hidden, self.num_layers - 1, skips[0] if skips else -1, self.multires, self.d_out,
+                              _lib.UDF_TYPES[self.udf_type], float(self.scale))
+
+    def packed(self, precision=None):
+        """Device buffer with the folded/permuted weights for `precision`; rebuilt when parameters change."""
+        prec = _lib.PRECISIONS[precision or self.precision]
+        gs, vs, bs = self._gvb()
+        _lib.require_cuda(vs[0], "UDFNetwork parameters")
+        key = (prec, vs[0].device, tuple(int(t._version) for t in gs + vs + bs), tuple(t.data_ptr() for t in vs))
+        hit = self._pack_cache.get(prec)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        L = _lib.lib()
+        cfg = self.net_config()
+        nbytes = C.c_size_t()
+        _lib.check(L.emap_packed_bytes(C.byref(cfg), prec, C.byref(nbytes)), "packed_bytes")
+        buf = hit[1] if (hit is not None and hit[1].numel() == nbytes.value and hit[1].device == vs[0].device) else \
+            torch.empty(nbytes.value, dtype=torch.uint8, device=vs[0].device)
+        n = len(vs)
+        arr = lambda ts: (C.c_void_p * n)(*[_lib.f32c(t.detach()).data_ptr() for t in ts])
+        keep = [[_lib.f32c(t.detach()) for t in ts] for ts in (gs, vs, bs)]  # keep contiguous copies alive
+        ga = (C.c_void_p * n)(*[t.data_ptr() for t in keep[0]])
+        va = (C.c_void_p * n)(*[t.data_ptr() for t in keep[1]])
+        ba = (C.c_void_p * n)(*[t.data_ptr() for t in keep[2]])
+        _lib.check(L.emap_pack_weights(C.byref(cfg), ga, va, ba, _lib.ptr(buf), prec, _lib.stream_ptr()), "pack_weights")
+        self._pack_cache[prec] = (key, buf)
+        return buf
+
+    # ---- HIP evaluation -----------------------------------------------------------------------
+    def _needs_autograd(self, x):
+        return torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
+
+    def hip_udf(self, x, with_grad=False, precision=None):
+        """(udf (P,1), grad (P,3) | None) from the fused kernel; no autograd."""
+        _lib.require_cuda(x, "x")
+        prec = _lib.PRECISIONS[precision or self.precision]
+        xs = _lib.f32c(x.detach().reshape(-1, 3))
+        P = xs.shape[0]
+        cfg = self.net_config()
+        buf = self.packed(precision)
+        udf = torch.empty(P, 1, device=xs.device, dtype=torch.float32)
+        L = _lib.lib()
+        if with_grad:
+            grad = torch.empty(P, 3, device=xs.device, dtype=torch.float32)
+            _lib.check(L.emap_udf_fwd_grad(C.byref(cfg), _lib.ptr(buf), prec, _lib.ptr(xs), P, _lib.ptr(udf), _lib.ptr(grad),
+                                          _lib.stream_ptr()), "udf_fwd_grad")
+            return udf, grad
+        _lib.check(L.emap_udf_fwd(C.byref(cfg), _lib.ptr(buf), prec, _lib.ptr(xs), P, _lib.ptr(udf), _lib.stream_ptr()), "udf_fwd")
+        return udf, None
+
+    # ---- reference interface ------------------------------------------------------------------
+    def udf_out(self, x):
+        if self.udf_type == "abs":
+            return torch.abs(x)
+        if self.udf_type == "square":
+            return x ** 2
+        return x
+
+    def forward(self, inputs):
+        """-> (out (P,d_out), PE (P,d0))   (udf_model.py:90-110)."""
+        _lib.require_cuda(inputs, "inputs")
+        _lib.lib()
+        if self._needs_autograd(inputs):
+            from ._interim_backward import udf_forward_torch
+            return udf_forward_torch(self, inputs)
+        udf, _ = self.hip_udf(inputs)
+        pe = self.embed_fn_fine(inputs.detach() * self.scale)
+        return udf, pe
+
+    def udf(self, x):
+        feature_out, pe = self.forward(x)
+        return feature_out[:, :1], feature_out[:, 1:], pe
+
+    def udf_hidden_appearance(self, x):
+        return self.forward(x)
+
+    def gradient(self, x):
+        """-> (P,1,3) grad_x udf   (udf_model.py:121-135; differentiable when grads are enabled)."""
+        _lib.require_cuda(x, "x")
+        _lib.lib()
+        if self._needs_autograd(x) and any(p.requires_grad for p in self.parameters()):
+            from ._interim_backward import udf_gradient_torch
+            return udf_gradient_torch(self, x)
+        _, g = self.hip_udf(x, with_grad=True)
+        return g.unsqueeze(1)
+
+
+class RenderingNetwork(nn.Module):
+    """Reference: src/models/udf_model.py:138-209.  Never instantiated by the reference runner
+    (SURVEY.md par. 2 #4); kept as a plain PyTorch module so the name and signature exist."""
+
+    def __init__(self, d_feature, mode, d_in, d_out, d_hidden, n_layers, weight_norm=True, multires_view=0,
+                 squeeze_out=True):
+        super().__init__()
+        self.mode, self.squeeze_out, self.d_out = mode, squeeze_out, d_out
+        dims = [d_in + d_feature] + [d_hidden for _ in range(n_layers)] + [d_out]
+        self.multires_view = multires_view if mode != "no_view_dir" else 0
+        if self.multires_view > 0:
+            dims[0] += 6 * multires_view
+        self.num_layers = len(dims)
+        for l in range(self.num_layers - 1):
+            lin = nn.Linear(dims[l], dims[l + 1])
+            if weight_norm:
+                lin = nn.utils.parametrizations.weight_norm(lin)
+            setattr(self, "lin" + str(l), lin)
+        self.relu = nn.ReLU()
+
+    def forward(self, points, normals, view_dirs, feature_vectors):
+        if self.multires_view > 0:
+            view_dirs = embed_torch(view_dirs, self.multires_view)
+        normals = normals.detach()
+        if self.mode == "idr":
+            x = torch.cat([points, view_dirs, normals, -1 * normals, feature_vectors], dim=-1)
+        elif self.mode == "no_view_dir":
+            x = torch.cat([points, normals, -1 * normals, feature_vectors], dim=-1)
+        else:
+            x = torch.cat([points, view_dirs, feature_vectors], dim=-1)
+        for l in range(self.num_layers - 1):
+            x = getattr(self, "lin" + str(l))(x)
+            if l < self.num_layers - 2:
+                x = self.relu(x)
+        return torch.sigmoid(x[:, : self.d_out]) if self.squeeze_out else x[:, : self.d_out]
+
+
+class SingleVarianceNetwork(nn.Module):
+    """Reference: src/models/udf_model.py:212-232."""
+
+    def __init__(self, init_val, requires_grad=True):
+        super().__init__()
+        self.variance = nn.Parameter(torch.Tensor([init_val]), requires_grad=requires_grad)
+        self.second_variance = nn.Parameter(torch.Tensor([init_val]), requires_grad=requires_grad)
+
+    def set_trainable(self):
+        self.variance.requires_grad = True
+        self.second_variance.requires_grad = True
+
+    def forward(self, x):
+        return torch.ones([len(x), 1], device=x.device) * torch.exp(self.variance * 10.0)
+
+    def get_secondvariance(self, x):
+        return torch.ones([len(x), 1], device=x.device) * torch.exp(self.second_variance * 10.0)
+
+
+class BetaNetwork(nn.Module):
+    """Reference: src/models/udf_model.py:235-286."""
+
+    def __init__(self, init_var_beta=0.1, init_var_gamma=0.1, init_var_zeta=0.05, beta_min=0.00005,
+                 requires_grad_beta=True, requires_grad_gamma=True, requires_grad_zeta=True):
+        super().__init__()
+        self.beta = nn.Parameter(torch.Tensor([init_var_beta]), requires_grad=requires_grad_beta)
+        self.gamma = nn.Parameter(torch.Tensor([init_var_gamma]), requires_grad=requires_grad_gamma)
+        self.zeta = nn.Parameter(torch.Tensor([init_var_zeta]), requires_grad=requires_grad_zeta)
+        self.beta_min = beta_min
+
+    def get_beta(self):
+        return torch.exp(self.beta * 10).clip(0, 1.0 / self.beta_min)
+
+    def get_gamma(self):
+        return torch.exp(self.gamma * 10)
+
+    def get_zeta(self):
+        return self.zeta.abs()
+
+    def set_beta_trainable(self):
+        self.beta.requires_grad = True
+
+    @torch.no_grad()
+    def set_gamma(self, x):
+        self.gamma = nn.Parameter(torch.Tensor([x]), requires_grad=self.gamma.requires_grad).to(self.gamma.device)
+
+    def forward(self):
+        return self.get_beta(), self.get_gamma(), self.get_zeta()

@@ -1,0 +1,208 @@
+"""Renderer with the reference interface (reference src/models/udf_renderer_blending.py:112-975),
+evaluated by libemap_hip: ``render()`` enqueues the coarse sampler, the MLP passes, the K
+occlusion-aware up-sampling steps, the final MLP value+gradient pass and the compositing kernel on the
+current stream in ONE C call with no host synchronisation.
+
+Supported configuration = what every EMAP conf selects (SURVEY.md par. 2 #5-#7):
+``sdf2alpha_type="numerical"``, ``upsampling_type="classical"``, ``use_unbias_render=True``,
+``use_norm_grad_for_cosine=False``, ``n_outside=0``.  Anything else raises at construction.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._interim_backward import RenderCoreInterim, DIFF_KEYS
+
+_PER_SAMPLE = ("weights", "alpha", "mid_z", "dists", "inside_sphere", "gradient_mag")
+
+
+def sample_pdf(bins, weights, n_samples, det=False):
+    """reference udf_renderer_blending.py:69-109 (deterministic u only - the hot path calls det=True)."""
+    if not det:
+        raise NotImplementedError("sample_pdf(det=False) is not on the EMAP render path")
+    _lib.require_cuda(bins, "bins")
+    b, w = _lib.f32c(bins), _lib.f32c(weights)
+    N, n = b.shape
+    out = torch.empty(N, n_samples, device=b.device, dtype=torch.float32)
+    _lib.check(_lib.lib().emap_sample_pdf(_lib.ptr(b), _lib.ptr(w), N, n, n_samples, _lib.ptr(out), None, None,
+                                          _lib.stream_ptr()), "sample_pdf")
+    return out
+
+
+class UDFRendererBlending:
+    def __init__(self, nerf, udf_network, deviation_network, beta_network, n_samples, n_importance, n_outside,
+                 up_sample_steps, perturb, sdf2alpha_type="numerical", upsampling_type="classical",
+                 sparse_scale_factor=25000, use_norm_grad_for_cosine=False, use_unbias_render=True, near_surface=0.05,
+                 device="cuda", precision=None):
+        if n_outside != 0 or nerf is not None:
+            raise NotImplementedError("n_outside>0 / background NeRF is dead code in the reference (SURVEY par. 2 #7)")
+        if sdf2alpha_type != "numerical" or upsampling_type != "classical" or not use_unbias_render or use_norm_grad_for_cosine:
+            raise NotImplementedError("only sdf2alpha_type='numerical', upsampling_type='classical', "
+                                      "use_unbias_render=True, use_norm_grad_for_cosine=False are on the hot path")
+        self.nerf = nerf
+        self.udf_network = udf_network
+        self.deviation_network = deviation_network
+        self.beta_network = beta_network
+        self.n_samples = n_samples
+        self.n_importance = n_importance
+        self.n_outside = n_outside
+        self.perturb = perturb
+        self.up_sample_steps = up_sample_steps
+        self.use_unbias_render = use_unbias_render
+        self.sdf2alpha_type = sdf2alpha_type
+        self.upsampling_type = upsampling_type
+        self.sparse_scale_factor = sparse_scale_factor
+        self.use_norm_grad_for_cosine = use_norm_grad_for_cosine
+        self.near_surface = near_surface
+        self.device = device
+        self.precision = precision  # None -> udf_network.precision
+        self._ws = {}
+        self._err = None
+
+    # ---- helpers ------------------------------------------------------------------------------
+    @property
+    def samples_per_ray(self):
+        m = self.n_importance // self.up_sample_steps if self.n_importance > 0 else 0
+        return self.n_samples + m * (self.up_sample_steps if m > 0 else 0)
+
+    def _params(self, N, cos_anneal_ratio, flip_saturation, background_rgb):
+        p = _lib.RenderParams()
+        p.n_rays, p.n_samples, p.n_importance, p.up_sample_steps = N, self.n_samples, self.n_importance, self.up_sample_steps
+        p.inv_s = p.beta = p.gamma = 0.0
+        p.cos_anneal_ratio = float(cos_anneal_ratio) if cos_anneal_ratio is not None else 0.0
+        p.has_cos_anneal = int(cos_anneal_ratio is not None)
+        p.flip_saturation = float(flip_saturation)
+        p.near_surface = float(self.near_surface)
+        p.sparse_scale = float(self.sparse_scale_factor)
+        p.has_background = int(background_rgb is not None)
+        p.background = 0.0
+        if background_rgb is not None:
+            bg = torch.as_tensor(background_rgb).reshape(-1)
+            if bg.numel() != 1 and not bool((bg == bg[0]).all()):
+                raise NotImplementedError("edge is single-channel: background_rgb must be a scalar / constant")
+            p.background = float(bg[0])
+        p.variance_dev = self.deviation_network.variance.data_ptr()
+        p.beta_dev = self.beta_network.beta.data_ptr()
+        p.gamma_dev = self.beta_network.gamma.data_ptr()
+        p.beta_min = float(self.beta_network.beta_min)
+        return p
+
+    def error_flags(self) -> int:
+        """Device error word (NaN in sample_pdf / gradient_error). Reading it synchronises: call it lazily."""
+        return 0 if self._err is None else int(self._err.item())
+
+    def check_errors(self):
+        f = self.error_flags()
+        if f:
+            self._err.zero_()
+            raise RuntimeError(f"emap_amd render: NaN detected on device (flags={f}: "
+                               f"{'z_samples ' if f & _lib.F_NAN_SAMPLES else ''}{'gradient_error' if f & _lib.F_NAN_GRADERR else ''})")
+
+    # ---- reference interface ------------------------------------------------------------------
+    def render(self, rays_o, rays_d, near, far, depth_scale, cos_anneal_ratio=None, perturb_overwrite=-1,
+               background_rgb=None, flip_saturation=0, color_maps=None, pose=None, fx=None, fy=None, img_index=None,
+               rays_uv=None, t_rand=None):
+        """reference udf_renderer_blending.py:679-800.  Extra keyword `t_rand` ((N,1) in [-0.5,0.5)) injects
+        the jitter draw (tests); otherwise it is drawn exactly like the reference: torch.rand([N,1]) on the
+        CPU generator (:719)."""
+        _lib.require_cuda(rays_o, "rays_o")
+        dev = rays_o.device
+        N = len(rays_o)
+        S = self.samples_per_ray
+        net = self.udf_network
+        prec_name = self.precision or net.precision
+        prec = _lib.PRECISIONS[prec_name]
+        ro, rd = _lib.f32c(rays_o.detach()), _lib.f32c(rays_d.detach())
+        if not isinstance(near, torch.Tensor):
+            near_t = torch.full((N,), float(near), device=dev, dtype=torch.float32)
+            far_t = torch.full((N,), float(far), device=dev, dtype=torch.float32)
+        else:
+            near_t = _lib.f32c(near.detach().to(dev)).reshape(-1).expand(N).contiguous()
+            far_t = _lib.f32c(far.detach().to(dev)).reshape(-1).expand(N).contiguous()
+        perturb = self.perturb if perturb_overwrite < 0 else perturb_overwrite
+        tr = None
+        if t_rand is not None:
+            tr = _lib.f32c(t_rand.to(dev)).reshape(-1)
+        elif perturb > 0:
+            tr = (torch.rand([N, 1]) - 0.5).to(dev).reshape(-1)
+        ds = _lib.f32c(depth_scale.detach().to(dev)).reshape(-1) if depth_scale is not None else None
+
+        # one flat output allocation, sliced into views
+        sizes = {"z_vals": N * S, "udf": N * S, "gradients": N * S * 3, "gradients_flip": N * S * 3, "edge": N, "depth": N,
+                 "weight_sum": N, "normals": N * 3, "scalars": 16}
+        for k in _PER_SAMPLE:
+            sizes[k] = N * S
+        flat = torch.empty(sum(sizes.values()), device=dev, dtype=torch.float32)
+        v, off = {}, 0
+        for k, n in sizes.items():
+            v[k] = flat[off:off + n]
+            off += n
+
+        p = self._params(N, cos_anneal_ratio, flip_saturation, background_rgb)
+        L = _lib.lib()
+        key = (N, dev)
+        ws = self._ws.get(key)
+        if ws is None:
+            nb = C.c_size_t()
+            _lib.check(L.emap_render_workspace_bytes(C.byref(p), C.byref(nb)), "render_workspace_bytes")
+            ws = torch.empty(nb.value, dtype=torch.uint8, device=dev)
+            self._ws = {key: ws}
+        if self._err is None or self._err.device != dev:
+            self._err = torch.zeros(1, dtype=torch.int32, device=dev)
+        co = _lib.CompositeOut()
+        for k in _PER_SAMPLE + ("gradients_flip", "edge", "depth", "weight_sum", "normals", "scalars"):
+            setattr(co, k, v[k].data_ptr())
+        cfg = net.net_config()
+        packed = net.packed(prec_name)
+        _lib.check(L.emap_render_fwd(C.byref(cfg), _lib.ptr(packed), prec, C.byref(p), _lib.ptr(ro), _lib.ptr(rd),
+                                     _lib.ptr(near_t), _lib.ptr(far_t), _lib.ptr(tr), _lib.ptr(ds), _lib.ptr(v["z_vals"]),
+                                     _lib.ptr(v["udf"]), _lib.ptr(v["gradients"]), C.byref(co), _lib.ptr(ws), ws.numel(),
+                                     _lib.ptr(self._err), _lib.stream_ptr()), "render_fwd")
+
+        out = {
+            "udf": v["udf"].view(N, S), "edge": v["edge"].view(N, 1), "weights": v["weights"].view(N, S),
+            "depth": v["depth"].view(N, 1), "gradient_error": v["scalars"][0], "gradient_error_near_surface": v["scalars"][1],
+            "normals": v["normals"].view(N, 3), "gradients": v["gradients"].view(N, S, 3),
+            "gradients_flip": v["gradients_flip"].view(N, S, 3), "gradient_mag": v["gradient_mag"].view(N, S),
+            "weight_sum": v["weight_sum"].view(N, 1),
+        }
+        z_vals = v["z_vals"].view(N, S)
+
+        params = [q for q in list(net.parameters()) + [self.deviation_network.variance, self.beta_network.beta,
+                                                       self.beta_network.gamma]]
+        if torch.is_grad_enabled() and any(q.requires_grad for q in params):
+            # INTERIM backward (SURVEY par. 8 f1): see emap_amd/_interim_backward.py
+            sample_dist = ((far_t - near_t) / self.n_samples).mean()
+            bg = None if background_rgb is None else torch.as_tensor(background_rgb, device=dev, dtype=torch.float32)
+            dsv = ds.view(N, 1) if ds is not None else torch.ones(N, 1, device=dev)
+            res = RenderCoreInterim.apply(self, ro, rd, z_vals, sample_dist, cos_anneal_ratio, bg, float(flip_saturation),
+                                          dsv, len(params), *params, *[out[k] for k in DIFF_KEYS])
+            out.update(dict(zip(DIFF_KEYS, res)))
+
+        sc = v["scalars"]
+        if torch.is_grad_enabled() and any(q.requires_grad for q in params[-3:]):
+            # differentiable w.r.t. variance/beta/gamma: ordinary torch expressions (:466-472,656-658)
+            inv_s = self.deviation_network(torch.zeros([1, 3], device=dev))[:, :1].clip(1e-6, 1e6)
+            s_val = (1.0 / inv_s).expand(N * S, 1)
+            beta_out = 1.0 / self.beta_network.get_beta().clip(1e-6, 1e6)
+            gamma_out = self.beta_network.get_gamma().clip(1e-6, 1e6)
+        else:
+            # inference: the same three numbers, written by the compositing kernel (no extra launches)
+            s_val = sc[8:9].view(1, 1).expand(N * S, 1)
+            beta_out = sc[9:10]
+            gamma_out = sc[10:11]
+        return {
+            "udf": out["udf"], "edge": out["edge"], "weight_sum": out["weight_sum"], "weight_sum_fg_bg": out["weight_sum"],
+            "depth": out["depth"], "variance": s_val, "beta": beta_out, "gamma": gamma_out,
+            "normals": out["normals"], "gradients": out["gradients"], "gradients_flip": out["gradients_flip"],
+            "weights": out["weights"], "gradient_error": out["gradient_error"],
+            "gradient_error_near_surface": out["gradient_error_near_surface"],
+            "inside_sphere": v["inside_sphere"].view(N, S), "gradient_mag": out["gradient_mag"],
+            "mid_z_vals": v["mid_z"].view(N, S), "dists": v["dists"].view(N, S),
+            # extras (not in the reference dict)
+            "z_vals": z_vals, "alpha": v["alpha"].view(N, S), "sparse_error": v["scalars"][2],
+            "eikonal_sums": v["scalars"][3:7],
+        }

@@ -1,0 +1,191 @@
+/* emap_hip.h - C ABI of libemap_hip.so, the MI355X (gfx950) render hot path of EMAP.
+ *
+ * EMAP (cvg/EMAP) is pure Python/PyTorch and has no FFI layer; the drop-in boundary is the
+ * Python class API of src/models/{udf_model,udf_renderer_blending,embedder,loss}.py (SURVEY.md
+ * par. 8b).  The entry points below are what a binding for that boundary needs: every one names the
+ * reference interface it replaces (file:line in the reference repo).  emap_amd/_lib.py binds them
+ * with ctypes; INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers unless the name ends in _host; tensors are fp32, contiguous,
+ *     row-major; index outputs are int64 (torch.long), like the reference's searchsorted / sort.
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*); no call synchronises,
+ *     allocates device memory or keeps a reference to a caller buffer after the work it enqueued.
+ *   - return value: 0 = ok, negative = EMAP_E_* (emap_last_error() has the text).  No C++ exception
+ *     crosses the boundary.
+ *   - the reference's NaN -> pdb.set_trace() convention (udf_renderer_blending.py:102-107,346-351,
+ *     632-633) is replaced by a device error word `err_flags` (int32[1], may be NULL) into which
+ *     kernels OR the EMAP_F_* bits; the host reads it lazily, never inside the hot path.
+ */
+#ifndef EMAP_HIP_H
+#define EMAP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EMAP_ABI_VERSION 1
+
+/* error codes */
+#define EMAP_OK 0
+#define EMAP_E_INVALID (-1)     /* bad argument / unsupported configuration */
+#define EMAP_E_LAUNCH (-2)      /* HIP launch error                          */
+#define EMAP_E_WORKSPACE (-3)   /* workspace too small                       */
+
+/* err_flags bits */
+#define EMAP_F_NAN_SAMPLES 1    /* sample_pdf produced NaN   (udf_renderer_blending.py:102)  */
+#define EMAP_F_NAN_GRADERR 2    /* gradient_error is NaN     (udf_renderer_blending.py:632)  */
+
+/* arithmetic mode of the MLP GEMMs (accumulation is always fp32) */
+#define EMAP_PREC_BF16 0        /* one bf16 MFMA pass                                        */
+#define EMAP_PREC_BF16X3 1      /* split bf16: a_hi*w_hi + a_lo*w_hi + a_hi*w_lo (~2^-17)     */
+
+/* udf_type (udf_model.py:82-88) */
+#define EMAP_UDF_ABS 0
+#define EMAP_UDF_SQUARE 1
+#define EMAP_UDF_SDF 2
+
+#define EMAP_MAX_LIN 12
+
+/* Constructor arguments of UDFNetwork that the kernels need (udf_model.py:8-21,24-45). */
+typedef struct EmapNetConfig {
+    int32_t d_hidden;   /* 128 or 256                                   */
+    int32_t n_lin;      /* number of Linear layers = n_layers + 1       */
+    int32_t skip_l;     /* layer whose input is cat([x, PE])/sqrt2, or -1 (skip_in=(4,) -> 4) */
+    int32_t multires;   /* 1..10 positional-encoding octaves            */
+    int32_t d_out;      /* must be 1                                    */
+    int32_t udf_type;   /* EMAP_UDF_*                                   */
+    float scale;        /* inputs * scale, udf / scale (udf_model.py:91,108) */
+} EmapNetConfig;
+
+int emap_abi_version(void);
+const char* emap_last_error(void);
+
+/* ---- weights -------------------------------------------------------------------------------
+ * Replaces the per-call weight_norm re-evaluation of nn.utils.parametrizations.weight_norm
+ * (udf_model.py:73-74): folds W = g*v/||v|| once, permutes it into MFMA fragment order and
+ * converts it for `prec`.  g[l] is [out,1], v[l] is [out,in], b[l] is [out] (state-dict
+ * original0/original1/bias).  The three pointer tables are HOST arrays of device pointers. */
+int emap_packed_bytes(const EmapNetConfig* cfg, int prec, size_t* bytes);
+int emap_pack_weights(const EmapNetConfig* cfg, const float* const* g_host, const float* const* v_host,
+                      const float* const* b_host, void* packed, int prec, void* stream);
+
+/* ---- fields --------------------------------------------------------------------------------
+ * emap_udf_fwd      : UDFNetwork.forward / .udf value  (udf_model.py:90-116)   x (P,3) -> udf (P)
+ * emap_udf_fwd_grad : + UDFNetwork.gradient            (udf_model.py:121-135)  -> grad (P,3)
+ * emap_embed        : Embedder.embed                   (embedder.py:34-35)     x (P,3) -> (P,3+6L) */
+int emap_udf_fwd(const EmapNetConfig* cfg, const void* packed, int prec, const float* x, int64_t P,
+                 float* udf, void* stream);
+int emap_udf_fwd_grad(const EmapNetConfig* cfg, const void* packed, int prec, const float* x, int64_t P,
+                      float* udf, float* grad3, void* stream);
+int emap_embed(const float* x, int64_t P, int multires, float* pe, void* stream);
+
+/* ---- sampler -------------------------------------------------------------------------------
+ * emap_sample_pdf    : sample_pdf(bins, weights, m, det=True)  (udf_renderer_blending.py:69-109)
+ *                      bins (N,n), weights (N,n-1) -> samples (N,m), inds int64 (N,m) (may be NULL)
+ * emap_upsample_step : up_sample_unbias                        (udf_renderer_blending.py:228-353)
+ *                      z,udf (N,n) -> z_new (N,m), inds (N,m) (may be NULL)
+ * emap_merge_sorted  : the cat + sort + gather of cat_z_vals   (udf_renderer_blending.py:361-375)
+ *                      z (N,n), z_new (N,m) [, udf (N,n), udf_new (N,m)] -> z_out, udf_out (N,n+m),
+ *                      perm int64 (N,n+m) (may be NULL); udf/udf_new/udf_out may be NULL (last=True) */
+int emap_sample_pdf(const float* bins, const float* weights, int N, int n, int m, float* samples,
+                    int64_t* inds, int32_t* err_flags, void* stream);
+int emap_upsample_step(const float* rays_o, const float* rays_d, const float* z, const float* udf, int N, int n,
+                       int m, const float* sample_dist_dev, float inv_s, float beta, float gamma, float* z_new,
+                       int64_t* inds, int32_t* err_flags, void* stream);
+int emap_merge_sorted(const float* z, const float* z_new, const float* udf, const float* udf_new, int N, int n,
+                      int m, float* z_out, float* udf_out, int64_t* perm, void* stream);
+
+/* ---- compositing ---------------------------------------------------------------------------
+ * The tail of render_core (udf_renderer_blending.py:435-455,463-677) after the MLP: given the
+ * sorted z_vals and (udf, grad) at the interval mid-points.  Scalars are the already-transformed
+ * inv_s = exp(10*variance).clip, beta, gamma (udf_renderer_blending.py:466-472).
+ * Per-sample outputs are (N,S); per-ray outputs (N) or (N,3); `scalars` receives
+ *   [0] gradient_error  [1] gradient_error_near_surface  [2] sparse_error
+ *   [3] sum(relax*err) [4] sum(relax) [5] sum(near*err) [6] sum(near)   (for cross-rank reduction)
+ *   [7] sum_rays sum_samples exp(-sparse_scale*udf)   [8] 1/inv_s  [9] 1/beta  [10] gamma  [11] inv_s
+ * Any output pointer may be NULL. */
+typedef struct EmapCompositeOut {
+    float* weights;        /* (N,S)   :593-602 */
+    float* alpha;          /* (N,S)   :545     */
+    float* mid_z;          /* (N,S)   :446     */
+    float* dists;          /* (N,S)   :435-444 */
+    float* inside_sphere;  /* (N,S)   :568     */
+    float* gradient_mag;   /* (N,S)   :463     */
+    float* gradients_flip; /* (N,S,3) :637     */
+    float* edge;           /* (N)     :606-609 */
+    float* depth;          /* (N)     :607 (times depth_scale if given, render() :786) */
+    float* weight_sum;     /* (N)     :604     */
+    float* normals;        /* (N,3)   :662     */
+    float* scalars;        /* (16)             */
+} EmapCompositeOut;
+
+int emap_composite_fwd(const float* rays_o, const float* rays_d, const float* z, const float* udf,
+                       const float* grad3, const float* depth_scale, int N, int S, const float* sample_dist_dev,
+                       float inv_s, float beta, float gamma, float cos_anneal_ratio, int has_cos_anneal,
+                       float flip_saturation, float near_surface, float sparse_scale, float background,
+                       int has_background, const EmapCompositeOut* out, float* partials /* (N,8) scratch */,
+                       int32_t* err_flags, void* stream);
+
+
+/* ---- fused forward render ------------------------------------------------------------------
+ * UDFRendererBlending.render (udf_renderer_blending.py:679-800) for upsampling_type="classical",
+ * use_unbias_render=True, n_outside=0: coarse z_vals (:705-720) -> importance_sample (:802-841) ->
+ * render_core (:418-677).  near/far are (N) device arrays; t_rand (N) may be NULL (no jitter).
+ * The whole sequence is enqueued on `stream` with no host synchronisation.
+ * z_vals (N,S), udf (N,S), grad3 (N,S,3) are outputs as well (S = n_samples + n_importance//steps*steps). */
+typedef struct EmapRenderParams {
+    int32_t n_rays;
+    int32_t n_samples;
+    int32_t n_importance;
+    int32_t up_sample_steps;
+    float inv_s, beta, gamma;
+    float cos_anneal_ratio;
+    int32_t has_cos_anneal;
+    float flip_saturation;
+    float near_surface;
+    float sparse_scale;
+    float background;
+    int32_t has_background;
+    /* optional: raw nn.Parameters on the device (variance, beta, gamma of SingleVarianceNetwork /
+     * BetaNetwork, udf_model.py:215,248-253).  When variance_dev != NULL the kernels evaluate
+     * inv_s = exp(10*variance).clip(1e-6,1e6), beta = exp(10*beta).clip(0,1/beta_min).clip(1e-6,1e6),
+     * gamma = exp(10*gamma).clip(1e-6,1e6) themselves (udf_renderer_blending.py:466-472) and ignore the
+     * three by-value fields above, so no device->host read of the parameters is ever needed. */
+    const float* variance_dev;
+    const float* beta_dev;
+    const float* gamma_dev;
+    float beta_min;
+    int32_t reserved;
+} EmapRenderParams;
+
+/* same, with inv_s/beta/gamma taken from raw device parameters (see EmapRenderParams) */
+int emap_composite_fwd_p(const float* rays_o, const float* rays_d, const float* z, const float* udf,
+                         const float* grad3, const float* depth_scale, int N, int S, const float* sample_dist_dev,
+                         const EmapRenderParams* p, const EmapCompositeOut* out, float* partials,
+                         int32_t* err_flags, void* stream);
+
+int emap_render_workspace_bytes(const EmapRenderParams* p, size_t* bytes);
+int emap_render_fwd(const EmapNetConfig* cfg, const void* packed, int prec, const EmapRenderParams* p,
+                    const float* rays_o, const float* rays_d, const float* near, const float* far,
+                    const float* t_rand, const float* depth_scale, float* z_vals, float* udf, float* grad3,
+                    const EmapCompositeOut* out, void* workspace, size_t workspace_bytes, int32_t* err_flags,
+                    void* stream);
+
+/* ---- measurement ----------------------------------------------------------------------------
+ * While enabled, emap_render_fwd brackets its dominant kernel (the final value+gradient MLP pass) with
+ * hipEvents on the launch stream; emap_profile_read (after the caller synchronised) returns the summed
+ * duration and the number of launches.  Used by bench.py for the roofline figure. */
+int emap_profile_enable(int on);
+int emap_profile_read(float* total_ms_host, int* launches_host);
+
+/* host-only: torch.linspace(start, end, steps) in fp32, the grid of sample_pdf's u / the coarse z_vals */
+void emap_linspace_host(float start, float end, int steps, float* out_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EMAP_HIP_H */

@@ -283,5 +283,21 @@ def g8_scalars():
          zeta=bet.get_zeta())
 
 
+def g9_seeded_init():
+    """Reference constructor under torch.manual_seed: the drop-in classes must consume the RNG identically."""
+    out = {}
+    for name, kw in (("d8w256L10", NETS["d8w256L10"][0]), ("d4w128L10", NETS["d4w128L10"][0])):
+        torch.manual_seed(1234)
+        net = UDFNetwork(scale=1.0, geometric_init=True, weight_norm=True, udf_type="abs", **kw)
+        for k, v in net.state_dict().items():
+            out[f"{name}.{k}.abs_sum"] = v.double().abs().sum()
+            out[f"{name}.{k}.head"] = v.reshape(-1)[:4].clone()
+            out[f"{name}.{k}.shape"] = np.array(v.shape)
+    save("g9_seeded_init", **out)
+
+
 if __name__ == "__main__":
-    g1_pe(); g2_mlp(); g3_sample_pdf(); g4_upsample_step(); g5_render(); g6_training(); g7_perturb(); g8_scalars()
+    only = sys.argv[1:]
+    for fn in (g1_pe, g2_mlp, g3_sample_pdf, g4_upsample_step, g5_render, g6_training, g7_perturb, g8_scalars, g9_seeded_init):
+        if not only or fn.__name__ in only:
+            fn()

@@ -1,0 +1,238 @@
+"""CPU-side tests of the boundary: the C-ABI library loads and exports every declared symbol, host-only
+entry points, the drop-in class surface (constructor signatures, state-dict keys, seeded init), the
+loud failure without a GPU, and the interim torch backward against the reference's gradients."""
+import ctypes as C
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden, t, net_state, NETS
+import emap_amd
+from emap_amd import _lib, synthetic
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "emap_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(emap_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    names = header_symbols()
+    assert len(names) >= 15
+    lib = C.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), f"libemap_hip.so does not export {n}"
+    # and the ctypes binding covers exactly the header
+    assert sorted(_lib.SYMBOLS) == names
+
+
+def test_abi_version_and_error_text():
+    L = _lib.lib()
+    assert L.emap_abi_version() == 1
+    cfg = _lib.NetConfig(200, 9, 4, 10, 1, 0, 1.0)
+    n = C.c_size_t()
+    assert L.emap_packed_bytes(C.byref(cfg), 0, C.byref(n)) == -1
+    assert b"d_hidden" in L.emap_last_error()
+    cfg = _lib.NetConfig(256, 9, 4, 10, 2, 0, 1.0)
+    assert L.emap_packed_bytes(C.byref(cfg), 0, C.byref(n)) == -1  # d_out must be 1
+
+
+@pytest.mark.parametrize("H,n_lin,multires,prec,expect_frags", [
+    (256, 9, 10, 0, 8 * 4 + 5 * 8 * 16 + 7 * 16 + 8 * 20 + 16),
+    (256, 9, 10, 1, 2 * (8 * 4 + 5 * 8 * 16 + 7 * 16 + 8 * 20 + 16)),
+    (128, 5, 10, 0, 4 * 4 + 2 * 4 * 8 + 3 * 8 + 12),
+])
+def test_packed_layout_size(H, n_lin, multires, prec, expect_frags):
+    L = _lib.lib()
+    cfg = _lib.NetConfig(H, n_lin, 4, multires, 1, 0, 1.0)
+    n = C.c_size_t()
+    assert L.emap_packed_bytes(C.byref(cfg), prec, C.byref(n)) == 0
+    hdr = ((2 * n_lin * H * 4 + 1023) // 1024) * 1024
+    assert n.value == hdr + expect_frags * 1024
+
+
+@pytest.mark.parametrize("m", [1, 2, 3, 8, 10, 12, 16, 32, 50, 64, 127, 128])
+def test_linspace_grid(m):
+    """The u grid of sample_pdf (:79-81) and the coarse z grid (:705) are torch.linspace in fp32.  ATen evaluates
+    it as start + step*i (first half) / end - step*(steps-1-i) (second half); its CPU kernel does so per SIMD
+    vector (arange from the vector's first element, possibly FMA-contracted), its CUDA kernel per element, so the
+    reference itself is only defined up to 1 ulp across machines.  The library uses the per-element form with
+    separately rounded multiply/add: bit-identical to the numpy restatement below, within 1 ulp of torch here."""
+    L = _lib.lib()
+    buf = (C.c_float * m)()
+    for a, b in ((0.0 + 0.5 / m, 1.0 - 0.5 / m), (0.0, 1.0)):
+        L.emap_linspace_host(a, b, m, buf)
+        got = np.array(list(buf), dtype=np.float32)
+        a32, b32 = np.float32(a), np.float32(b)
+        if m == 1:
+            exp = np.array([a32])
+        else:
+            step = np.float32((b32 - a32) / np.float32(m - 1))
+            i = np.arange(m)
+            up = (a32 + (step * i.astype(np.float32)).astype(np.float32)).astype(np.float32)
+            dn = (b32 - (step * (m - 1 - i).astype(np.float32)).astype(np.float32)).astype(np.float32)
+            exp = np.where(i < m // 2, up, dn).astype(np.float32)
+        assert np.array_equal(got, exp)
+        ref = torch.linspace(a, b, steps=m).numpy()
+        ulp = np.spacing(np.maximum(np.abs(ref), np.float32(1e-30)))
+        assert np.all(np.abs(got - ref) <= ulp), (m, np.abs(got - ref).max())
+
+
+def test_state_dict_matches_reference_layout():
+    g = load_golden("g6_training_3")
+    net = emap_amd.UDFNetwork(3, 1, 256, 8, skip_in=(4,), multires=10, bias=0.5, scale=1.0, geometric_init=True,
+                              weight_norm=True, udf_type="abs")
+    keys = list(net.state_dict())
+    ref_keys = [k[len("grad."):] for k in g if k.startswith("grad.lin")]
+    assert keys == ref_keys  # same names, same order (Adam param groups, checkpoints)
+    for k, v in net.state_dict().items():
+        assert tuple(v.shape) == g["grad." + k].shape
+    assert [n for n, _ in emap_amd.SingleVarianceNetwork(0.3).named_parameters()] == ["variance", "second_variance"]
+    assert [n for n, _ in emap_amd.BetaNetwork().named_parameters()] == ["beta", "gamma", "zeta"]
+    # loads the synthetic state (same dict the reference loaded when the goldens were made)
+    kw, state = net_state("d8w256L10")
+    net.load_state_dict(state)
+
+
+@pytest.mark.parametrize("name", ["d8w256L10", "d4w128L10"])
+def test_seeded_init_identical_to_reference(name):
+    """Same nn.Linear/init call sequence as reference udf_model.py:39-76 -> same parameters for a seed."""
+    g = load_golden("g9_seeded_init")
+    kw = NETS[name][0]
+    torch.manual_seed(1234)
+    net = emap_amd.UDFNetwork(scale=1.0, geometric_init=True, weight_norm=True, udf_type="abs", **kw)
+    for k, v in net.state_dict().items():
+        assert tuple(v.shape) == tuple(g[f"{name}.{k}.shape"])
+        assert torch.equal(v.reshape(-1)[:4], t(g[f"{name}.{k}.head"]))
+        assert float(v.double().abs().sum()) == pytest.approx(float(g[f"{name}.{k}.abs_sum"]), rel=1e-12)
+
+
+def test_scalar_networks_match_reference_values():
+    g = load_golden("g8_scalars")
+    dev = emap_amd.SingleVarianceNetwork(0.3)
+    bet = emap_amd.BetaNetwork(0.5, 0.3, 0.3, 0.00005, True, True, False)
+    assert torch.allclose(dev(torch.zeros(5, 3)), t(g["inv_s"]))
+    assert torch.allclose(bet.get_beta(), t(g["beta"]))
+    assert torch.allclose(bet.get_gamma(), t(g["gamma"]))
+    assert not bet.zeta.requires_grad and bet.beta.requires_grad
+    dev2 = emap_amd.SingleVarianceNetwork(0.3, requires_grad=False)
+    dev2.set_trainable()
+    assert dev2.variance.requires_grad
+
+
+def test_product_path_fails_loudly_without_gpu():
+    kw, state = net_state("d4w128L10")
+    net = emap_amd.UDFNetwork(**kw)
+    net.load_state_dict(state)
+    x = torch.zeros(4, 3)
+    for fn in (lambda: net(x), lambda: net.udf(x), lambda: net.gradient(x), lambda: net.hip_udf(x)):
+        with pytest.raises(RuntimeError, match="no CPU fallback|needs tensors on"):
+            with torch.no_grad():
+                fn()
+    with pytest.raises(RuntimeError):
+        net.gradient(x)  # also with autograd enabled
+    r = emap_amd.UDFRendererBlending(None, net, emap_amd.SingleVarianceNetwork(0.3), emap_amd.BetaNetwork(), 32, 32, 0, 4, 1.0)
+    ro, rd, near, far, ds = synthetic.make_rays(4)
+    with pytest.raises(RuntimeError, match="no CPU fallback|needs tensors on"):
+        r.render(ro, rd, near, far, ds)
+    with pytest.raises(RuntimeError):
+        emap_amd.sample_pdf(torch.rand(2, 8).sort(-1)[0], torch.rand(2, 7), 4, det=True)
+
+
+def test_unsupported_configurations_raise():
+    kw, _ = net_state("d4w128L10")
+    net = emap_amd.UDFNetwork(**kw)
+    a = (net, emap_amd.SingleVarianceNetwork(0.3), emap_amd.BetaNetwork())
+    with pytest.raises(NotImplementedError):
+        emap_amd.UDFRendererBlending(None, *a, 32, 32, 4, 4, 1.0)  # n_outside > 0
+    with pytest.raises(NotImplementedError):
+        emap_amd.UDFRendererBlending(None, *a, 32, 32, 0, 4, 1.0, upsampling_type="mix")
+    with pytest.raises(NotImplementedError):
+        emap_amd.UDFRendererBlending(None, *a, 32, 32, 0, 4, 1.0, sdf2alpha_type="theorical")
+    with pytest.raises(NotImplementedError):
+        emap_amd.UDFNetwork(3, 4, 128, 4, multires=10).net_config()  # d_out > 1
+
+
+def test_dropin_aliases_reference_import_paths():
+    import emap_amd.dropin as dropin
+    saved = {k: sys.modules.get(k) for k in list(sys.modules) if k == "src" or k.startswith("src.")}
+    try:
+        names = dropin.install()
+        assert "src.models.udf_model" in names
+        from src.models.udf_model import UDFNetwork, SingleVarianceNetwork, BetaNetwork  # noqa: F401
+        from src.models.udf_renderer_blending import UDFRendererBlending, sample_pdf  # noqa: F401
+        from src.models.loss import EdgeLoss  # noqa: F401
+        from src.models.embedder import get_embedder  # noqa: F401
+        assert UDFNetwork is emap_amd.UDFNetwork and UDFRendererBlending is emap_amd.UDFRendererBlending
+    finally:
+        for k in [k for k in sys.modules if k == "src" or k.startswith("src.")]:
+            del sys.modules[k]
+        sys.modules.update({k: v for k, v in saved.items() if v is not None})
+
+
+def test_edge_loss():
+    a, b = torch.rand(7, 1), torch.rand(7, 1)
+    assert torch.allclose(emap_amd.EdgeLoss("mse")(a, b), ((a - b) ** 2).mean())
+    assert torch.allclose(emap_amd.EdgeLoss("l1")(a, b), (a - b).abs().mean())
+
+
+# ---- interim backward (torch graph, runs on the GPU in the product; exercised here on CPU tensors) ----------
+def _mk_cpu(name):
+    kw, state = net_state(name)
+    net = emap_amd.UDFNetwork(**kw)
+    net.load_state_dict(state)
+    return net
+
+
+@pytest.mark.parametrize("name", ["d8w256L10", "d4w128L10", "d8w256L6"])
+def test_interim_torch_mlp_matches_reference(name):
+    from emap_amd._interim_backward import udf_forward_torch, udf_gradient_torch
+    g = load_golden("g2_mlp")
+    net = _mk_cpu(name)
+    x = t(g["x"])
+    out, pe = udf_forward_torch(net, x)
+    assert torch.allclose(out, t(g[f"{name}.out"]), rtol=1e-5, atol=1e-6)
+    assert torch.equal(pe, t(g[f"{name}.pe"]))
+    gr = udf_gradient_torch(net, x.clone()).detach()
+    ref = t(g[f"{name}.grad"])
+    assert float((gr - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("ci", [0, 1, 2, 3])
+def test_interim_backward_matches_reference_gradients(ci):
+    """dL/dtheta through emap_amd._interim_backward.render_core_torch on the z_vals of the forward pass ==
+    the reference's loss.backward() (goldens G6)."""
+    from emap_amd._interim_backward import render_core_torch
+    from oracle import emap_oracle as O
+    g = load_golden(f"g6_training_{ci}")
+    name = str(g["netname"])
+    kw, state = net_state(name)
+    net = _mk_cpu(name)
+    dev, bet = emap_amd.SingleVarianceNetwork(0.3), emap_amd.BetaNetwork(0.5, 0.3, 0.3, 5e-5, True, True, False)
+    ns, ni, steps = [int(v) for v in g["cfg"]]
+    r = emap_amd.UDFRendererBlending(None, net, dev, bet, ns, ni, 0, steps, 1.0, device="cpu")
+    a = [t(g[k]) for k in ("rays_o", "rays_d", "near", "far", "depth_scale")]
+    cfg = O.UDFConfig(d_hidden=kw["d_hidden"], n_layers=kw["n_layers"], multires=kw["multires"])
+    with torch.no_grad():  # the forward sampler (HIP in the product) - here the oracle provides z_vals
+        z = O.render(state, cfg, O.RenderConfig(ns, ni, steps), *a, torch.tensor([0.3]), torch.tensor([0.5]),
+                     torch.tensor([0.3]), cos_anneal_ratio=float(g["cos_anneal_ratio"]),
+                     flip_saturation=float(g["flip_saturation"]))["z_vals"]
+    sd = ((a[3] - a[2]) / ns).mean()
+    out = render_core_torch(r, a[0], a[1], z, sd, float(g["cos_anneal_ratio"]), None, float(g["flip_saturation"]))
+    ew, igr, igr_ns = [float(v) for v in g["weights3"]]
+    loss = emap_amd.EdgeLoss("mse")(out["edge"], t(g["true_edge"])) * ew + out["gradient_error_near_surface"] * igr_ns \
+        + out["gradient_error"] * igr
+    loss.backward()
+    assert float(loss) == pytest.approx(float(g["loss"]), rel=2e-5)
+    for k, p in net.named_parameters():
+        ref = t(g["grad." + k])
+        assert float((p.grad - ref).abs().max()) <= 1e-4 * float(ref.abs().max()) + 1e-8, k
+    for k, p in (("variance", dev.variance), ("beta", bet.beta), ("gamma", bet.gamma)):
+        ref = t(g["grad." + k])
+        got = p.grad if p.grad is not None else torch.zeros(1)
+        assert float((got - ref).abs().max()) <= 1e-4 * float(ref.abs().max()) + 1e-8, k
