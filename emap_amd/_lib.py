@@ -16,7 +16,9 @@ LIB_PATH = os.path.join(_HERE, "lib", "libemap_hip.so")
 
 PREC_BF16 = 0
 PREC_BF16X3 = 1
-PRECISIONS = {"bf16": PREC_BF16, "bf16x3": PREC_BF16X3}
+PREC_F16 = 2
+PREC_F16X3 = 3
+PRECISIONS = {"bf16": PREC_BF16, "bf16x3": PREC_BF16X3, "f16": PREC_F16, "f16x3": PREC_F16X3}
 UDF_TYPES = {"abs": 0, "square": 1, "sdf": 2}
 MAX_LIN = 12
 

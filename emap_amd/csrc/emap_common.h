@@ -40,7 +40,7 @@ struct NetLayout {
     float scale;
     int32_t total_frags;
     int32_t bias_off_bytes, rowscale_off_bytes, frag_off_bytes;
-    int32_t pad0;
+    int32_t is_f16;
     LayerDesc layer[EMAP_MAX_LIN];
 };
 

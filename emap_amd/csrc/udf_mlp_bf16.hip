@@ -1,0 +1,8 @@
+// udf_mlp_bf16.hip - instantiates the fused UDF-MLP kernels (udf_mlp_kernel.inc) for EMAP_PREC_BF16.
+#include "udf_mlp_kernel.inc"
+namespace emap {
+int launch_mlp_bf16(const NetLayout& L, const void* packed, const PointSource& src, int64_t P, float* udf, float* grad3,
+                      hipStream_t st) {
+    return launch_mlp_mode<EMAP_PREC_BF16>(L, packed, src, P, udf, grad3, st);
+}
+}  // namespace emap

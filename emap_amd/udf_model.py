@@ -26,7 +26,7 @@ import torch.nn as nn
 from . import _lib
 from .embedder import get_embedder, embed_torch
 
-DEFAULT_PRECISION = os.environ.get("EMAP_PRECISION", "bf16x3")
+DEFAULT_PRECISION = os.environ.get("EMAP_PRECISION", "f16x3")
 
 
 class UDFNetwork(nn.Module):
@@ -144,6 +144,8 @@ class UDFNetwork(nn.Module):
         buf = self.packed(precision)
         udf = torch.empty(P, 1, device=xs.device, dtype=torch.float32)
         L = _lib.lib()
+        if P == 0:
+            return udf, (torch.empty(0, 3, device=xs.device, dtype=torch.float32) if with_grad else None)
         if with_grad:
             grad = torch.empty(P, 3, device=xs.device, dtype=torch.float32)
             _lib.check(L.emap_udf_fwd_grad(C.byref(cfg), _lib.ptr(buf), prec, _lib.ptr(xs), P, _lib.ptr(udf), _lib.ptr(grad),

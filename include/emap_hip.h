@@ -42,6 +42,8 @@ extern "C" {
 /* arithmetic mode of the MLP GEMMs (accumulation is always fp32) */
 #define EMAP_PREC_BF16 0        /* one bf16 MFMA pass                                        */
 #define EMAP_PREC_BF16X3 1      /* split bf16: a_hi*w_hi + a_lo*w_hi + a_hi*w_lo (~2^-17)     */
+#define EMAP_PREC_F16 2         /* one fp16 MFMA pass (11-bit mantissa; |values| must stay < 65504) */
+#define EMAP_PREC_F16X3 3       /* split fp16, three passes (~2^-22): the mode of the 1e-4 parity gate */
 
 /* udf_type (udf_model.py:82-88) */
 #define EMAP_UDF_ABS 0

@@ -26,7 +26,7 @@ def mk(name, scale=1.0, precision="bf16x3"):
 g2 = load_golden("g2_mlp")
 x = t(g2["x"])
 for name in ["d8w256L10", "d8w256L6", "d4w128L10", "d8w256L10_init"]:
-    for prec in ["bf16x3", "bf16"]:
+    for prec in ["f16x3", "bf16x3", "f16", "bf16"]:
         net, state, cfg = mk(name, precision=prec)
         with torch.no_grad():
             u, g = net.hip_udf(x.to(dev), with_grad=True)
@@ -77,7 +77,7 @@ G5 = {"c64_50_5": "d8w256L10", "c64_64_4": "d8w256L10", "c32_32_4_small": "d4w12
 for case, name in G5.items():
     g = load_golden("g5_render_" + case)
     ns, ni, steps = [int(v) for v in g["cfg"]]
-    for prec in ["bf16x3", "bf16"]:
+    for prec in ["f16x3", "bf16x3", "f16", "bf16"]:
         net, state, cfg = mk(name, precision=prec)
         devn = emap_amd.SingleVarianceNetwork(0.3).to(dev); bet = emap_amd.BetaNetwork(0.5, 0.3, 0.3, 5e-5, True, True, False).to(dev)
         r = emap_amd.UDFRendererBlending(None, net, devn, bet, ns, ni, 0, steps, 1.0, device=dev)
@@ -86,36 +86,8 @@ for case, name in G5.items():
             out = r.render(*a, cos_anneal_ratio=1.0, perturb_overwrite=0, flip_saturation=0.9)
         torch.cuda.synchronize()
         zref = t(g[f"z_after_step{steps-1}"])
-        zm = (out["z_vals"].cpu() != zref).float().mean().item()
+        zm = ((out["z_vals"].cpu() - zref).abs().max(dim=1)[0] > 1e-5).float().mean().item()
         s = " ".join(f"{k}:{rel(out[k], t(g['out.'+k]).reshape(out[k].shape)):.1e}" for k in ["edge", "depth", "weights", "normals", "gradient_error", "gradient_error_near_surface", "udf", "gradients", "mid_z_vals", "dists", "inside_sphere", "gradient_mag", "variance", "beta", "gamma"])
-        print(f"render {case} {prec}: z mismatch frac {zm:.4f} | {s} | err {r.error_flags()}")
+        print(f"render {case} {prec}: rays with moved samples {zm:.3f} | {s} | err {r.error_flags()}")
 
-# timing at the north-star size
-for prec in ["bf16", "bf16x3"]:
-    net, state, cfg = mk("d8w256L10", precision=prec)
-    devn = emap_amd.SingleVarianceNetwork(0.3).to(dev); bet = emap_amd.BetaNetwork(0.5, 0.3, 0.3, 5e-5, True, True, False).to(dev)
-    for N in (512, 4096):
-        r = emap_amd.UDFRendererBlending(None, net, devn, bet, 64, 64, 0, 4, 1.0, device=dev)
-        ro, rd, near, far, ds = [v.to(dev) for v in synthetic.make_rays(N, seed=1)]
-        tr = synthetic.make_t_rand(N).to(dev)
-        with torch.no_grad():
-            for _ in range(5): r.render(ro, rd, near, far, ds, cos_anneal_ratio=1.0, flip_saturation=0.9, t_rand=tr)
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(20): r.render(ro, rd, near, far, ds, cos_anneal_ratio=1.0, flip_saturation=0.9, t_rand=tr)
-            e1.record(); torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / 20
-        print(f"render {prec} N={N} S=128: {ms*1e3:.1f} us  -> {N*128/ms*1e3:.3e} ray-samples/s  ({N*128*2639296/ms*1e3/1e12:.1f} TF algorithmic)")
-    x = torch.rand(65536, 3, device=dev) * 2 - 1
-    with torch.no_grad():
-        for wg in (False, True):
-            for _ in range(3): net.hip_udf(x, with_grad=wg)
-            torch.cuda.synchronize(); e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(10): net.hip_udf(x, with_grad=wg)
-            e1.record(); torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1) / 10
-            F = 918016 * (2 if wg else 1)
-            print(f"  mlp {prec} grad={wg} P=65536: {ms*1e3:.1f} us  {65536*F/ms*1e3/1e12:.1f} TF algorithmic")
 print("PROBE DONE")
