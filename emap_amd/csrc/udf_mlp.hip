@@ -2,6 +2,8 @@
 // fused UDF-MLP kernels.  The kernels themselves live in udf_mlp_kernel.inc, instantiated per precision mode in
 // udf_mlp_{bf16,bf16x3,f16,f16x3}.hip.
 #include "emap_common.h"
+#include <stdlib.h>
+#include <string.h>
 
 namespace emap {
 
@@ -160,18 +162,34 @@ int launch_pack(const NetLayout& L, const float* const* g, const float* const* v
     return check_launch("pack_weights");
 }
 
-int launch_mlp_bf16(const NetLayout&, const void*, const PointSource&, int64_t, float*, float*, hipStream_t);
-int launch_mlp_bf16x3(const NetLayout&, const void*, const PointSource&, int64_t, float*, float*, hipStream_t);
-int launch_mlp_f16(const NetLayout&, const void*, const PointSource&, int64_t, float*, float*, hipStream_t);
-int launch_mlp_f16x3(const NetLayout&, const void*, const PointSource&, int64_t, float*, float*, hipStream_t);
+int launch_mlp_bf16(const NetLayout&, const void*, const PointSource&, int64_t, float*, float*, hipStream_t, int);
+int launch_mlp_bf16x3(const NetLayout&, const void*, const PointSource&, int64_t, float*, float*, hipStream_t, int);
+int launch_mlp_f16(const NetLayout&, const void*, const PointSource&, int64_t, float*, float*, hipStream_t, int);
+int launch_mlp_f16x3(const NetLayout&, const void*, const PointSource&, int64_t, float*, float*, hipStream_t, int);
+
+// kernel variant: 0 = "classic" (column-split waves, weights shared through LDS), 1 = "fs" (feature-split waves).
+// Measured on MI355X (d8 w256): the split-precision modes are faster with fs at every size; the single-pass modes
+// only while the launch is latency-bound (fs re-reads the weights from L2 per 16..64 columns).
+// EMAP_MLP_KERNEL=classic|fs forces one variant for A/B measurements.
+static int mlp_variant(int prec, int64_t P, bool grad) {
+    static int forced = -2;
+    if (forced == -2) {
+        const char* e = getenv("EMAP_MLP_KERNEL");
+        forced = !e ? -1 : (!strcmp(e, "classic") ? 0 : (!strcmp(e, "fs") ? 1 : -1));
+    }
+    if (forced >= 0) return forced;
+    if (prec == EMAP_PREC_BF16X3 || prec == EMAP_PREC_F16X3) return 1;
+    if (grad) return P < 16384 ? 1 : 0;
+    return P < 49152 ? 1 : 0;
+}
 
 int launch_mlp(const NetLayout& L, const void* packed, int prec, const PointSource& src, int64_t P, float* udf,
                float* grad3, hipStream_t st) {
     switch (prec) {
-        case EMAP_PREC_BF16: return launch_mlp_bf16(L, packed, src, P, udf, grad3, st);
-        case EMAP_PREC_BF16X3: return launch_mlp_bf16x3(L, packed, src, P, udf, grad3, st);
-        case EMAP_PREC_F16: return launch_mlp_f16(L, packed, src, P, udf, grad3, st);
-        case EMAP_PREC_F16X3: return launch_mlp_f16x3(L, packed, src, P, udf, grad3, st);
+        case EMAP_PREC_BF16: return launch_mlp_bf16(L, packed, src, P, udf, grad3, st, mlp_variant(prec, P, grad3 != nullptr));
+        case EMAP_PREC_BF16X3: return launch_mlp_bf16x3(L, packed, src, P, udf, grad3, st, mlp_variant(prec, P, grad3 != nullptr));
+        case EMAP_PREC_F16: return launch_mlp_f16(L, packed, src, P, udf, grad3, st, mlp_variant(prec, P, grad3 != nullptr));
+        case EMAP_PREC_F16X3: return launch_mlp_f16x3(L, packed, src, P, udf, grad3, st, mlp_variant(prec, P, grad3 != nullptr));
     }
     set_error("unknown precision mode %d", prec);
     return EMAP_E_INVALID;
