@@ -169,7 +169,7 @@ def main():
                                    f"UDF MLP d=8 w=256 multires=10, forward render()",
                        "rays_per_gpu": a.rays, "samples_per_ray": S, "precision": a.precision,
                        "parallelism": f"dp{world} over rays, no collective in forward"},
-            "roofline": {"bound": "mfma", "kernel": f"udf_mlp_kernel<256,{a.precision},grad> (final value+grad pass)",
+            "roofline": {"bound": "mfma", "kernel": ("udf_mlp_fs_kernel" if a.precision.endswith("x3") else "udf_mlp_kernel") + f"<256,{a.precision},grad> (final value+grad pass)",
                          "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
                          "avg_launch_us": k_avg_s * 1e6, "launches": kn.value,
                          "algorithmic_flops_per_launch": flops_launch, "traffic": None},
