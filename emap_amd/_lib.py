@@ -24,6 +24,7 @@ MAX_LIN = 12
 
 F_NAN_SAMPLES = 1
 F_NAN_GRADERR = 2
+F_MLP_NONFINITE = 4
 
 
 class NetConfig(C.Structure):

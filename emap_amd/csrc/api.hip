@@ -219,7 +219,7 @@ int emap_render_fwd(const EmapNetConfig* cfg, const void* packed, int prec, cons
         PointSource src;
         memset(&src, 0, sizeof(src));
         src.rays_o = rays_o; src.rays_d = rays_d; src.z = zc; src.n_per_ray = Sc; src.mid = 0; src.sample_dist = sample_dist;
-        rc = launch_mlp(L, packed, prec, src, (int64_t)N * Sc, ubuf[0], nullptr, st);
+        rc = launch_mlp(L, packed, prec, src, (int64_t)N * Sc, ubuf[0], nullptr, st, err_flags);
         if (rc) return rc;
         int cur = 0, n = Sc;
         for (int i = 0; i < steps; ++i) {
@@ -232,7 +232,7 @@ int emap_render_fwd(const EmapNetConfig* cfg, const void* packed, int prec, cons
             if (rc) return rc;
             if (!last) {
                 src.z = z_new; src.n_per_ray = m;
-                rc = launch_mlp(L, packed, prec, src, (int64_t)N * m, udf_new, nullptr, st);
+                rc = launch_mlp(L, packed, prec, src, (int64_t)N * m, udf_new, nullptr, st, err_flags);
                 if (rc) return rc;
                 rc = launch_merge(zbuf[cur], z_new, ubuf[cur], udf_new, N, n, m, zbuf[cur ^ 1], ubuf[cur ^ 1], nullptr, st);
             } else {
@@ -250,7 +250,7 @@ int emap_render_fwd(const EmapNetConfig* cfg, const void* packed, int prec, cons
     fin.rays_o = rays_o; fin.rays_d = rays_d; fin.z = z_vals; fin.n_per_ray = S; fin.mid = 1; fin.sample_dist = sample_dist;
     const bool prof = g_prof_on && g_prof_n < PROF_MAX;
     if (prof) (void)hipEventRecord(g_prof_ev[g_prof_n][0], st);
-    rc = launch_mlp(L, packed, prec, fin, (int64_t)N * S, udf, grad3, st);
+    rc = launch_mlp(L, packed, prec, fin, (int64_t)N * S, udf, grad3, st, err_flags);
     if (prof) { (void)hipEventRecord(g_prof_ev[g_prof_n][1], st); ++g_prof_n; }
     if (rc) return rc;
     return launch_composite(rays_o, rays_d, z_vals, udf, grad3, depth_scale, N, S, sample_dist, p->inv_s, p->beta, p->gamma,

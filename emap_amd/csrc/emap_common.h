@@ -63,6 +63,6 @@ struct PointSource {
 };
 
 int launch_mlp(const NetLayout& L, const void* packed, int prec, const PointSource& src, int64_t P,
-               float* udf, float* grad3, hipStream_t st);
+               float* udf, float* grad3, hipStream_t st, int32_t* err_flags = nullptr);
 
 }  // namespace emap

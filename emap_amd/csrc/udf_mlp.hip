@@ -162,10 +162,10 @@ int launch_pack(const NetLayout& L, const float* const* g, const float* const* v
     return check_launch("pack_weights");
 }
 
-int launch_mlp_bf16(const NetLayout&, const void*, const PointSource&, int64_t, float*, float*, hipStream_t, int);
-int launch_mlp_bf16x3(const NetLayout&, const void*, const PointSource&, int64_t, float*, float*, hipStream_t, int);
-int launch_mlp_f16(const NetLayout&, const void*, const PointSource&, int64_t, float*, float*, hipStream_t, int);
-int launch_mlp_f16x3(const NetLayout&, const void*, const PointSource&, int64_t, float*, float*, hipStream_t, int);
+int launch_mlp_bf16(const NetLayout&, const void*, const PointSource&, int64_t, float*, float*, hipStream_t, int, int32_t*);
+int launch_mlp_bf16x3(const NetLayout&, const void*, const PointSource&, int64_t, float*, float*, hipStream_t, int, int32_t*);
+int launch_mlp_f16(const NetLayout&, const void*, const PointSource&, int64_t, float*, float*, hipStream_t, int, int32_t*);
+int launch_mlp_f16x3(const NetLayout&, const void*, const PointSource&, int64_t, float*, float*, hipStream_t, int, int32_t*);
 
 // kernel variant: 0 = "classic" (column-split waves, weights shared through LDS), 1 = "fs" (feature-split waves).
 // Measured on MI355X (d8 w256): the split-precision modes are faster with fs at every size; the single-pass modes
@@ -184,12 +184,12 @@ static int mlp_variant(int prec, int64_t P, bool grad) {
 }
 
 int launch_mlp(const NetLayout& L, const void* packed, int prec, const PointSource& src, int64_t P, float* udf,
-               float* grad3, hipStream_t st) {
+               float* grad3, hipStream_t st, int32_t* err_flags) {
     switch (prec) {
-        case EMAP_PREC_BF16: return launch_mlp_bf16(L, packed, src, P, udf, grad3, st, mlp_variant(prec, P, grad3 != nullptr));
-        case EMAP_PREC_BF16X3: return launch_mlp_bf16x3(L, packed, src, P, udf, grad3, st, mlp_variant(prec, P, grad3 != nullptr));
-        case EMAP_PREC_F16: return launch_mlp_f16(L, packed, src, P, udf, grad3, st, mlp_variant(prec, P, grad3 != nullptr));
-        case EMAP_PREC_F16X3: return launch_mlp_f16x3(L, packed, src, P, udf, grad3, st, mlp_variant(prec, P, grad3 != nullptr));
+        case EMAP_PREC_BF16: return launch_mlp_bf16(L, packed, src, P, udf, grad3, st, mlp_variant(prec, P, grad3 != nullptr), err_flags);
+        case EMAP_PREC_BF16X3: return launch_mlp_bf16x3(L, packed, src, P, udf, grad3, st, mlp_variant(prec, P, grad3 != nullptr), err_flags);
+        case EMAP_PREC_F16: return launch_mlp_f16(L, packed, src, P, udf, grad3, st, mlp_variant(prec, P, grad3 != nullptr), err_flags);
+        case EMAP_PREC_F16X3: return launch_mlp_f16x3(L, packed, src, P, udf, grad3, st, mlp_variant(prec, P, grad3 != nullptr), err_flags);
     }
     set_error("unknown precision mode %d", prec);
     return EMAP_E_INVALID;

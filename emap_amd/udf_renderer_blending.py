@@ -98,8 +98,9 @@ class UDFRendererBlending:
         f = self.error_flags()
         if f:
             self._err.zero_()
-            raise RuntimeError(f"emap_amd render: NaN detected on device (flags={f}: "
-                               f"{'z_samples ' if f & _lib.F_NAN_SAMPLES else ''}{'gradient_error' if f & _lib.F_NAN_GRADERR else ''})")
+            raise RuntimeError(f"emap_amd render: non-finite values detected on device (flags={f}: "
+                               f"{'z_samples ' if f & _lib.F_NAN_SAMPLES else ''}{'gradient_error ' if f & _lib.F_NAN_GRADERR else ''}"
+                               f"{'MLP output (fp16 range exceeded? use precision=bf16x3) ' if f & _lib.F_MLP_NONFINITE else ''})")
 
     # ---- reference interface ------------------------------------------------------------------
     def render(self, rays_o, rays_d, near, far, depth_scale, cos_anneal_ratio=None, perturb_overwrite=-1,

@@ -38,6 +38,8 @@ extern "C" {
 /* err_flags bits */
 #define EMAP_F_NAN_SAMPLES 1    /* sample_pdf produced NaN   (udf_renderer_blending.py:102)  */
 #define EMAP_F_NAN_GRADERR 2    /* gradient_error is NaN     (udf_renderer_blending.py:632)  */
+#define EMAP_F_MLP_NONFINITE 4  /* the MLP produced inf/NaN (fp16 modes: an activation or tangent left fp16's range;
+                                   use EMAP_PREC_BF16X3 / EMAP_PREC_BF16 for such a network)          */
 
 /* arithmetic mode of the MLP GEMMs (accumulation is always fp32) */
 #define EMAP_PREC_BF16 0        /* one bf16 MFMA pass                                        */

@@ -137,6 +137,25 @@ def test_mlp_all_tile_geometries_agree(P):
     assert rel(u_all[:2048], ur) <= 1e-4 and rel(g_all[:2048], gr) <= 1e-4
 
 
+def test_extraction_query_pattern():
+    """The second consumer of the field kernels (SURVEY par. 8 f2): get_udf_normals_grid queries `udf(pts)[0]` on a dense
+    grid in 4096-point batches and `gradient()` (normalised) on jittered neighbourhoods (extract_pointcloud.py:55-90)."""
+    net, state, cfg = mk("d8w256L10", "f16x3")
+    lin = torch.linspace(-1, 1, 16)
+    grid = torch.stack(torch.meshgrid(lin, lin, lin, indexing="ij"), -1).reshape(-1, 3)
+    with torch.no_grad():
+        u = torch.cat([net.udf(b.to(DEV))[0] for b in grid.split(4096)]).cpu()
+    ur = O.udf_value(state, cfg, grid)
+    assert rel(u, ur) <= 1e-4
+    near = grid[(ur[:, 0] < ur[:, 0].median())][:64]
+    nb = near[:, None, :] + 0.005 * torch.randn(64, 50, 3, generator=torch.Generator().manual_seed(0))
+    with torch.no_grad():
+        gd = net.gradient(nb.reshape(-1, 3).to(DEV)).squeeze(1)
+        gd = torch.nn.functional.normalize(gd, dim=-1).cpu()
+    gr = torch.nn.functional.normalize(O.udf_value_and_grad(state, cfg, nb.reshape(-1, 3))[1], dim=-1)
+    assert float((gd - gr).abs().max()) <= 2e-4
+
+
 def test_embedder_vs_golden():
     g = load_golden("g1_pe")
     for L in (10, 6):
@@ -156,6 +175,25 @@ def test_weight_repack_after_parameter_update():
     st = {k: v.detach().cpu() for k, v in net.state_dict().items()}
     ur = O.udf_value(st, cfg, x)
     assert rel(u1, ur) <= 1e-4 and rel(u0, ur) > 1e-3
+
+
+def test_fp16_range_overflow_raises_device_flag():
+    """A network whose activations leave fp16's range must not fail silently in the fp16 modes (the split-bf16 mode
+    handles it): the render raises through the device error word."""
+    kw, state = net_state("d4w128L10")
+    big = {k: (v * 3000.0 if k.endswith("original0") and k.startswith("lin1.") else v) for k, v in state.items()}
+    ro, rd, near, far, ds = [v.to(DEV) for v in synthetic.make_rays(64, seed=2)]
+    for prec, must_flag in (("f16x3", True), ("bf16x3", False)):
+        net = emap_amd.UDFNetwork(precision=prec, **kw)
+        net.load_state_dict(big)
+        r = mk_renderer(net.to(DEV), 32, 32, 4)
+        with torch.no_grad():
+            r.render(ro, rd, near, far, ds, cos_anneal_ratio=1.0, perturb_overwrite=0)
+        flagged = bool(r.error_flags() & _lib.F_MLP_NONFINITE)
+        assert flagged == must_flag, prec
+        if must_flag:
+            with pytest.raises(RuntimeError, match="bf16x3"):
+                r.check_errors()
 
 
 # ---------------------------------------------------------------------------------------- sampler
