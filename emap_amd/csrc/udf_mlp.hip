@@ -167,20 +167,18 @@ int launch_mlp_bf16x3(const NetLayout&, const void*, const PointSource&, int64_t
 int launch_mlp_f16(const NetLayout&, const void*, const PointSource&, int64_t, float*, float*, hipStream_t, int, int32_t*);
 int launch_mlp_f16x3(const NetLayout&, const void*, const PointSource&, int64_t, float*, float*, hipStream_t, int, int32_t*);
 
-// kernel variant: 0 = "classic" (column-split waves, weights shared through LDS), 1 = "fs" (feature-split waves).
-// Measured on MI355X (d8 w256): the split-precision modes are faster with fs at every size; the single-pass modes
-// only while the launch is latency-bound (fs re-reads the weights from L2 per 16..64 columns).
-// EMAP_MLP_KERNEL=classic|fs forces one variant for A/B measurements.
+// kernel variant: 0 = "classic" (column-split waves, weights shared through LDS, one wave per SIMD),
+// 1 = "fs" (feature-split waves, one workgroup per CU), 2 = "fs2" (feature-split, two/three workgroups per CU).
+// EMAP_MLP_KERNEL=classic|fs|fs2 forces one variant for A/B measurements.
 static int mlp_variant(int prec, int64_t P, bool grad) {
     static int forced = -2;
     if (forced == -2) {
         const char* e = getenv("EMAP_MLP_KERNEL");
-        forced = !e ? -1 : (!strcmp(e, "classic") ? 0 : (!strcmp(e, "fs") ? 1 : -1));
+        forced = !e ? -1 : (!strcmp(e, "classic") ? 0 : (!strcmp(e, "fs") ? 1 : (!strcmp(e, "fs2") ? 2 : -1)));
     }
     if (forced >= 0) return forced;
-    if (prec == EMAP_PREC_BF16X3 || prec == EMAP_PREC_F16X3) return 1;
-    if (grad) return P < 16384 ? 1 : 0;
-    return P < 49152 ? 1 : 0;
+    (void)prec; (void)P; (void)grad;
+    return 2;   // fs2 (two or three workgroups per CU) measured fastest or equal at every size and mode on MI355X
 }
 
 int launch_mlp(const NetLayout& L, const void* packed, int prec, const PointSource& src, int64_t P, float* udf,
