@@ -12,7 +12,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libemap_hip.so")
+LIB_PATH = os.environ.get("EMAP_HIP_LIB") or os.path.join(_HERE, "lib", "libemap_hip.so")   # env override: A/B builds
 
 PREC_BF16 = 0
 PREC_BF16X3 = 1

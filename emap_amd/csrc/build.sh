@@ -2,7 +2,7 @@
 # Build libemap_hip.so for gfx950 (MI355X).  hipcc cross-compiles without a GPU.
 set -e
 cd "$(dirname "$0")"
-OUT=../lib
+OUT=${EMAP_OUT:-../lib}
 mkdir -p "$OUT"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function ${EMAP_HIPCC_FLAGS}"

@@ -15,6 +15,11 @@ kw, state = net_state("d8w256L10")
 net = emap_amd.UDFNetwork(scale=1.0, precision=prec, **kw); net.load_state_dict(state); net = net.to(dev)
 x = torch.rand(P, 3, device=dev) * 2 - 1
 with torch.no_grad():
+    net.hip_udf(x, with_grad=wg)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     for _ in range(reps): net.hip_udf(x, with_grad=wg)
+    e1.record()
 torch.cuda.synchronize()
-print("done")
+print(f"{prec} grad={int(wg)} P={P}: {e0.elapsed_time(e1) / reps * 1e3:.1f} us")
