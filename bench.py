@@ -155,9 +155,12 @@ def main():
     if rank == 0:
         ms_per_step = dt / a.steps * 1e3
         value = a.rays * world * S / (dt / a.steps)
-        # dominant kernel: udf_mlp_fs2_kernel<256, prec, 4, GRAD> over rays*S points; algorithmic work = value +
+        # dominant kernel: the value+grad MLP launch over rays*S points; algorithmic work = value +
         # reverse-mode input gradient = 2F per point (SURVEY par. 8d)
         flops_launch = a.rays * S * 2 * F_POINT
+        # udf_mlp.hip:mlp_variant: reverse-sweep kernel for grad launches of >= 16384 points (not bf16x3), else forward mode
+        dominant_kernel = (f"udf_mlp_rev_kernel<256,{a.precision}>" if (a.rays * S >= 16384 and a.precision != "bf16x3")
+                           else f"udf_mlp_fs2_kernel<256,{a.precision},4,grad>")
         ach = flops_launch / k_avg_s / 1e12 if k_avg_s > 0 else 0.0
         line = {
             "metric": "ray-samples/sec (UDF MLP + composite)", "value": value, "unit": "ray-samples/s",
@@ -169,7 +172,7 @@ def main():
                                    f"UDF MLP d=8 w=256 multires=10, forward render()",
                        "rays_per_gpu": a.rays, "samples_per_ray": S, "precision": a.precision,
                        "parallelism": f"dp{world} over rays, no collective in forward"},
-            "roofline": {"bound": "mfma", "kernel": f"udf_mlp_fs2_kernel<256,{a.precision},4,grad> (final value+grad pass)",
+            "roofline": {"bound": "mfma", "kernel": dominant_kernel + " (final value+grad pass)",
                          "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
                          "avg_launch_us": k_avg_s * 1e6, "launches": kn.value,
                          "algorithmic_flops_per_launch": flops_launch, "traffic": None},

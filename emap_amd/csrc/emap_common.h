@@ -41,12 +41,22 @@ struct NetLayout {
     int32_t total_frags;
     int32_t bias_off_bytes, rowscale_off_bytes, frag_off_bytes;
     int32_t is_f16;
+    // transposed section (reverse-mode d(udf)/dx, udf_mlp_rev_kernel): W_l^T fragments for the backward GEMMs
+    //   t_off[l]   first fragment of layer l's hidden-row block  [row pair][K-step over out features][t][part], l >= 1
+    //   tpe_off[l] first fragment of layer l's PE-row block      [pe pair 0..1][K-step][t][part], l in {0, skip_l}
+    // and the last layer's single real row as fp32 (the backward sweep's seed).  has_rev = 0 when the topology is not
+    // covered (skip layer == last layer): the forward-mode kernels are used then.
+    int32_t has_rev, t_total_frags, t_frag_off_bytes, wlast_off_bytes;
+    int32_t t_off[EMAP_MAX_LIN], tpe_off[EMAP_MAX_LIN];
     LayerDesc layer[EMAP_MAX_LIN];
 };
 
 // returns 0 or EMAP_E_INVALID (error text set)
 int build_layout(const EmapNetConfig* cfg, int prec, NetLayout* L);
-inline size_t layout_bytes(const NetLayout& L) { return (size_t)L.frag_off_bytes + (size_t)L.total_frags * FRAG_BYTES; }
+inline size_t layout_bytes(const NetLayout& L) {
+    return L.has_rev ? (size_t)L.t_frag_off_bytes + (size_t)L.t_total_frags * FRAG_BYTES
+                     : (size_t)L.frag_off_bytes + (size_t)L.total_frags * FRAG_BYTES;
+}
 
 // launchers implemented in the .hip files
 int launch_pack(const NetLayout& L, const float* const* g, const float* const* v, const float* const* b,
@@ -62,7 +72,13 @@ struct PointSource {
     const float* sample_dist;  // device scalar (mid=1)
 };
 
+// scratch: device buffer of at least rev_scratch_bytes(L) for the reverse-mode grad kernel, or nullptr (a stream-ordered
+// temporary is allocated for the launch)
 int launch_mlp(const NetLayout& L, const void* packed, int prec, const PointSource& src, int64_t P,
-               float* udf, float* grad3, hipStream_t st, int32_t* err_flags = nullptr);
+               float* udf, float* grad3, hipStream_t st, int32_t* err_flags = nullptr, void* scratch = nullptr);
+constexpr int REV_MAX_WG = 768;      // persistent workgroups of the reverse-mode kernel (3 per CU)
+inline size_t rev_scratch_bytes(const NetLayout& L) {   // sigmoid stash: [workgroup][layer][pair][4][64 lanes x 16 B]
+    return L.has_rev ? (size_t)REV_MAX_WG * (size_t)(L.n_lin - 1) * (size_t)(L.H / 32) * 4096 : 0;
+}
 
 }  // namespace emap

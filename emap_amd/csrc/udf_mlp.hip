@@ -106,6 +106,87 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackArgs a) {
     else *reinterpret_cast<bf16x8*>(dst) = outv;
 }
 
+// Transposed fragments for the reverse sweep: A operand of  delta_in = W_l^T * delta_z_l.
+//   hidden rows: row f = 32*p + 16*t + i is input feature f of layer l (natural order, = the C-fragment row of the
+//                forward output a_{l-1}, so sigma' stashed by the forward sweep lines up lane for lane);
+//   PE rows:     row (tile tau = 2*pp + t, i = 4*gc + r) is PE slot (sp = pp, gc, e = 4*t + r) - the slot lane group gc
+//                itself produced in the forward PE block;
+//   k element (s, g, e) is output feature 16*(2s + e/4) + 4g + e%4 of layer l (the usual permutation).
+__global__ __launch_bounds__(256) void pack_t_kernel(const PackArgs a) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long F = gid >> 6;
+    const int lane = (int)(gid & 63);
+    if (F >= a.L.t_total_frags) return;
+    const int H = a.L.H, NP = a.L.nparts, d0 = a.L.d0, M = a.L.multires, NKS = H / 32;
+    // locate the block
+    int l = -1; bool pe = false; int base = 0;
+    for (int q = 0; q < a.L.n_lin; ++q) {
+        if (q >= 1 && q < a.L.n_lin - 1) {
+            const int n = ((a.L.layer[q].in_prev + 31) / 32) * NKS * 2 * NP;
+            if (F >= a.L.t_off[q] && F < a.L.t_off[q] + n) { l = q; pe = false; base = a.L.t_off[q]; }
+        }
+        if (q == 0 || q == a.L.skip_l) {
+            const int n = 2 * NKS * 2 * NP;
+            if (F >= a.L.tpe_off[q] && F < a.L.tpe_off[q] + n) { l = q; pe = true; base = a.L.tpe_off[q]; }
+        }
+    }
+    if (l < 0) return;
+    const LayerDesc Ld = a.L.layer[l];
+    int idx = (int)(F - base);
+    const int part = idx % NP; idx /= NP;
+    const int t = idx & 1; idx >>= 1;
+    const int s = idx % NKS;
+    const int p = idx / NKS;
+    const int i = lane & 15, g = lane >> 4;
+    const float* rs = reinterpret_cast<const float*>(a.packed + a.L.rowscale_off_bytes);
+    const float mult = (l == a.L.skip_l) ? 0.70710678118654752440f : 1.0f;
+    const int n_in = a.in_dim[l];
+    int col = -1;   // column of W_l this row stands for
+    if (!pe) {
+        const int f = 32 * p + 16 * t + i;
+        if (f < Ld.in_prev) col = f;
+    } else {
+        const int gc = i >> 2, r = i & 3, e_pe = 4 * t + r;
+        const int q = 4 * p + (e_pe >> 1), ang = 8 * gc + q, kind = e_pe & 1;
+        int pcol = -1;
+        if (ang < 3 * M) {
+            const int k = ang / 3, c = ang - 3 * k;
+            pcol = 3 + 6 * k + (kind ? 3 + c : c);
+        } else if (ang == 3 * M) {
+            pcol = kind ? 1 : 0;
+        } else if (ang == 3 * M + 1) {
+            pcol = kind ? -1 : 2;
+        }
+        if (pcol >= 0 && pcol < d0) col = (l == 0) ? pcol : Ld.in_prev + pcol;
+    }
+    const bool f16 = a.L.is_f16 != 0;
+    bf16x8 outv;
+    f16x8 outh;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int o = 16 * (2 * s + (e >> 2)) + 4 * g + (e & 3);
+        float w = 0.f;
+        if (o < Ld.out_dim && col >= 0 && col < n_in) w = rs[l * H + o] * a.v[l][(size_t)o * n_in + col] * mult;
+        const __bf16 hi = (__bf16)w;
+        outv[e] = (part == 0) ? hi : (__bf16)(w - (float)hi);
+        const _Float16 hh = (_Float16)w;
+        outh[e] = (part == 0) ? hh : (_Float16)((w - (float)hh) * 2048.0f);
+    }
+    char* dst = a.packed + a.L.t_frag_off_bytes + F * FRAG_BYTES + lane * 16;
+    if (f16) *reinterpret_cast<f16x8*>(dst) = outh;
+    else *reinterpret_cast<bf16x8*>(dst) = outv;
+}
+
+// fp32 copy of the last layer's real row (times its weight-norm scale): the seed of the reverse sweep
+__global__ __launch_bounds__(256) void pack_wlast_kernel(const PackArgs a) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    const int H = a.L.H, l = a.L.n_lin - 1;
+    if (f >= H) return;
+    const float* rs = reinterpret_cast<const float*>(a.packed + a.L.rowscale_off_bytes);
+    float* wl = reinterpret_cast<float*>(a.packed + a.L.wlast_off_bytes);
+    wl[f] = (f < a.L.layer[l].in_prev) ? rs[l * H] * a.v[l][f] : 0.f;
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
@@ -143,6 +224,17 @@ int build_layout(const EmapNetConfig* cfg, int prec, NetLayout* L) {
     L->rowscale_off_bytes = cfg->n_lin * H * 4;
     L->frag_off_bytes = ((2 * cfg->n_lin * H * 4 + 1023) / 1024) * 1024;
     if (chunks > MAX_CHUNKS || frag > 65535) { set_error("network too large for the chunk table"); return EMAP_E_INVALID; }
+    // transposed section for the reverse sweep
+    L->has_rev = (cfg->skip_l < cfg->n_lin - 1) ? 1 : 0;
+    L->wlast_off_bytes = L->frag_off_bytes + frag * FRAG_BYTES;
+    L->t_frag_off_bytes = L->wlast_off_bytes + ((H * 4 + 1023) / 1024) * 1024;
+    int tf = 0;
+    for (int l = 0; l < cfg->n_lin; ++l) {
+        L->t_off[l] = -1; L->tpe_off[l] = -1;
+        if (l >= 1 && l < cfg->n_lin - 1) { L->t_off[l] = tf; tf += ((L->layer[l].in_prev + 31) / 32) * (H / 32) * 2 * L->nparts; }
+        if (l == 0 || l == cfg->skip_l) { L->tpe_off[l] = tf; tf += 2 * (H / 32) * 2 * L->nparts; }
+    }
+    L->t_total_frags = L->has_rev ? tf : 0;
     return EMAP_OK;
 }
 
@@ -159,35 +251,49 @@ int launch_pack(const NetLayout& L, const float* const* g, const float* const* v
     hipLaunchKernelGGL(rowscale_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, a);
     const long long threads = (long long)L.total_frags * 64;
     hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, a);
+    if (L.has_rev) {
+        const long long tthreads = (long long)L.t_total_frags * 64;
+        hipLaunchKernelGGL(pack_t_kernel, dim3((unsigned)((tthreads + 255) / 256)), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(pack_wlast_kernel, dim3((L.H + 255) / 256), dim3(256), 0, st, a);
+    }
     return check_launch("pack_weights");
 }
 
-int launch_mlp_bf16(const NetLayout&, const void*, const PointSource&, int64_t, float*, float*, hipStream_t, int, int32_t*);
-int launch_mlp_bf16x3(const NetLayout&, const void*, const PointSource&, int64_t, float*, float*, hipStream_t, int, int32_t*);
-int launch_mlp_f16(const NetLayout&, const void*, const PointSource&, int64_t, float*, float*, hipStream_t, int, int32_t*);
-int launch_mlp_f16x3(const NetLayout&, const void*, const PointSource&, int64_t, float*, float*, hipStream_t, int, int32_t*);
+int launch_mlp_bf16(const NetLayout&, const void*, const PointSource&, int64_t, float*, float*, hipStream_t, int, int32_t*, void*);
+int launch_mlp_bf16x3(const NetLayout&, const void*, const PointSource&, int64_t, float*, float*, hipStream_t, int, int32_t*, void*);
+int launch_mlp_f16(const NetLayout&, const void*, const PointSource&, int64_t, float*, float*, hipStream_t, int, int32_t*, void*);
+int launch_mlp_f16x3(const NetLayout&, const void*, const PointSource&, int64_t, float*, float*, hipStream_t, int, int32_t*, void*);
 
 // kernel variant: 0 = "classic" (column-split waves, weights shared through LDS, one wave per SIMD),
-// 1 = "fs" (feature-split waves, one workgroup per CU), 2 = "fs2" (feature-split, two/three workgroups per CU).
-// EMAP_MLP_KERNEL=classic|fs|fs2 forces one variant for A/B measurements.
-static int mlp_variant(int prec, int64_t P, bool grad) {
-    static int forced = -2;
+// 1 = "fs" (feature-split waves, one workgroup per CU), 2 = "fs2" (feature-split, two/three workgroups per CU),
+// 3 = "rev" (grad launches only: fs2-shaped forward + reverse sweep, udf_mlp_rev.inc).
+// EMAP_MLP_KERNEL=classic|fs|fs2 forces one forward-mode variant, EMAP_GRAD_MODE=fwd|rev picks how d(udf)/dx is
+// computed (A/B measurements).
+static int mlp_variant(const NetLayout& L, int prec, int64_t P, bool grad) {
+    static int forced = -2, grad_mode = -2;
     if (forced == -2) {
         const char* e = getenv("EMAP_MLP_KERNEL");
         forced = !e ? -1 : (!strcmp(e, "classic") ? 0 : (!strcmp(e, "fs") ? 1 : (!strcmp(e, "fs2") ? 2 : -1)));
+        const char* gm = getenv("EMAP_GRAD_MODE");
+        grad_mode = !gm ? -1 : (!strcmp(gm, "fwd") ? 0 : (!strcmp(gm, "rev") ? 1 : -1));
     }
+    // reverse mode halves the MFMA work of a grad launch but a tile is two dependent sweeps: it wins once every CU has a
+    // workgroup (measured crossover between 8k and 32k points).  bf16x3 stays on the forward-mode kernel: its reverse
+    // instantiation is not run-to-run deterministic with two workgroups per CU (open issue, DESIGN.md par. 3.1).
+    if (grad && L.has_rev && forced < 0 && grad_mode != 0 && prec != EMAP_PREC_BF16X3 && (P >= 16384 || grad_mode == 1)) return 3;
     if (forced >= 0) return forced;
-    (void)prec; (void)P; (void)grad;
+    (void)prec; (void)P;
     return 2;   // fs2 (two or three workgroups per CU) measured fastest or equal at every size and mode on MI355X
 }
 
 int launch_mlp(const NetLayout& L, const void* packed, int prec, const PointSource& src, int64_t P, float* udf,
-               float* grad3, hipStream_t st, int32_t* err_flags) {
+               float* grad3, hipStream_t st, int32_t* err_flags, void* scratch) {
+    const int v = mlp_variant(L, prec, P, grad3 != nullptr);
     switch (prec) {
-        case EMAP_PREC_BF16: return launch_mlp_bf16(L, packed, src, P, udf, grad3, st, mlp_variant(prec, P, grad3 != nullptr), err_flags);
-        case EMAP_PREC_BF16X3: return launch_mlp_bf16x3(L, packed, src, P, udf, grad3, st, mlp_variant(prec, P, grad3 != nullptr), err_flags);
-        case EMAP_PREC_F16: return launch_mlp_f16(L, packed, src, P, udf, grad3, st, mlp_variant(prec, P, grad3 != nullptr), err_flags);
-        case EMAP_PREC_F16X3: return launch_mlp_f16x3(L, packed, src, P, udf, grad3, st, mlp_variant(prec, P, grad3 != nullptr), err_flags);
+        case EMAP_PREC_BF16: return launch_mlp_bf16(L, packed, src, P, udf, grad3, st, v, err_flags, scratch);
+        case EMAP_PREC_BF16X3: return launch_mlp_bf16x3(L, packed, src, P, udf, grad3, st, v, err_flags, scratch);
+        case EMAP_PREC_F16: return launch_mlp_f16(L, packed, src, P, udf, grad3, st, v, err_flags, scratch);
+        case EMAP_PREC_F16X3: return launch_mlp_f16x3(L, packed, src, P, udf, grad3, st, v, err_flags, scratch);
     }
     set_error("unknown precision mode %d", prec);
     return EMAP_E_INVALID;

@@ -11,5 +11,5 @@ for l in sys.stdin:
     for k in ['VGPRs:','AGPRs:','ScratchSize [bytes/lane]:','Occupancy [waves/SIMD]:','SGPRs Spill:','LDS Size']:
         if k in l and cur: d[k]=l.split(k)[1].split()[0]
     if 'LDS Size' in l and cur:
-        print(cur.replace('_ZN4emap14udf_mlp_kernel','mlp')[:48].ljust(48), 'V',d.get('VGPRs:'),'A',d.get('AGPRs:'),'scr',d.get('ScratchSize [bytes/lane]:'),'occ',d.get('Occupancy [waves/SIMD]:'),'sspill',d.get('SGPRs Spill:'))
+        print(cur.replace('_ZN4emap14udf_mlp_kernel','mlp')[:64].ljust(64), 'V',d.get('VGPRs:'),'A',d.get('AGPRs:'),'scr',d.get('ScratchSize [bytes/lane]:'),'occ',d.get('Occupancy [waves/SIMD]:'),'sspill',d.get('SGPRs Spill:'))
 "

@@ -42,7 +42,7 @@ for d in glob.glob(os.path.join(src, f"pmc_{prec}_*")):
     agg = collections.defaultdict(list)
     for did, cs in by.items():
         kn = names[did]
-        if "udf_mlp" in kn and "true" in kn.split("udf_mlp")[1][:48]:
+        if "udf_mlp_rev_kernel" in kn or ("udf_mlp" in kn and "true" in kn.split("udf_mlp")[1][:48]):
             for c, v in cs.items():
                 agg[c].append(v)
     for c, v in agg.items():

@@ -122,6 +122,34 @@ def test_mlp_ragged_sizes_vs_oracle(P):
         assert rel(ub, ur) <= tol, prec
 
 
+@pytest.mark.parametrize("name,scale", [("d8w256L10", 1.0), ("d8w256L6", 1.0), ("d8w256L10_init", 1.7)])
+def test_reverse_mode_gradient(name, scale):
+    """Large grad launches (>= 16384 points) run the reverse-sweep kernel (udf_mlp_rev.inc), smaller ones the forward-mode
+    tangent kernel: both are UDFNetwork.gradient (udf_model.py:121-135) and must agree with the oracle and with each
+    other; the reverse kernel (persistent workgroups, sigma' stashed through global memory) must be run-to-run
+    deterministic, also with several tiles per workgroup (70001 points: ragged last tile, > 2 tiles per workgroup)."""
+    net, state, cfg = mk(name, "f16x3", scale=scale)
+    gen = torch.Generator().manual_seed(11)
+    x = (torch.rand(70001, 3, generator=gen) * 2.2 - 1.1).to(DEV)
+    with torch.no_grad():
+        u, g = net.hip_udf(x, with_grad=True)                  # reverse mode
+        u2, g2 = net.hip_udf(x, with_grad=True)
+        us, gs = net.hip_udf(x[:8192], with_grad=True)         # forward mode (same points)
+        ut, gt = net.hip_udf(x[-4097:], with_grad=True)        # forward mode on the tail incl. the ragged tile
+    assert torch.equal(u, u2) and torch.equal(g, g2)
+    assert rel(u[:8192], us) <= 2e-6 and rel(g[:8192], gs) <= 5e-5
+    assert rel(u[-4097:], ut) <= 2e-6 and rel(g[-4097:], gt) <= 5e-5
+    ur, gr = O.udf_value_and_grad(state, cfg, x[:2048].cpu())
+    assert rel(u[:2048], ur) <= 1e-4 and rel(g[:2048], gr) <= 1e-4
+    for prec, tu, tg in (("bf16", 2e-2, 8e-2), ("f16", 3e-3, 1e-2)):
+        nb, _, _ = mk(name, prec, scale=scale)
+        with torch.no_grad():
+            ub, gb = nb.hip_udf(x[:20000], with_grad=True)      # reverse mode, single-pass arithmetic
+            ub2, gb2 = nb.hip_udf(x[:20000], with_grad=True)
+        assert torch.equal(ub, ub2) and torch.equal(gb, gb2)
+        assert rel(ub[:2048], ur) <= tu and rel(gb[:2048], gr) <= tg, prec
+
+
 @pytest.mark.parametrize("P", [8192, 32768, 70000])
 def test_mlp_all_tile_geometries_agree(P):
     """The launcher picks the tile geometry from P; all geometries must give the same numbers (bf16 and bf16x3)."""
