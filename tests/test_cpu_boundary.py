@@ -42,18 +42,23 @@ def test_abi_version_and_error_text():
     assert L.emap_packed_bytes(C.byref(cfg), 0, C.byref(n)) == -1  # d_out must be 1
 
 
-@pytest.mark.parametrize("H,n_lin,multires,prec,expect_frags", [
-    (256, 9, 10, 0, 8 * 4 + 5 * 8 * 16 + 7 * 16 + 8 * 20 + 16),
-    (256, 9, 10, 1, 2 * (8 * 4 + 5 * 8 * 16 + 7 * 16 + 8 * 20 + 16)),
-    (128, 5, 10, 0, 4 * 4 + 2 * 4 * 8 + 3 * 8 + 12),
+@pytest.mark.parametrize("H,n_lin,multires,prec,expect_frags,expect_tfrags", [
+    # forward fragments; transposed fragments of the reverse sweep: hidden rows of layers 1..n_lin-2 (7 row pairs for the
+    # skip layer) + 2 PE row pairs for layer 0 and the skip layer, each x (H/32 K-steps) x 2 tiles x parts
+    (256, 9, 10, 0, 8 * 4 + 5 * 8 * 16 + 7 * 16 + 8 * 20 + 16, 6 * 8 * 16 + 7 * 16 + 2 * 2 * 16),
+    (256, 9, 10, 1, 2 * (8 * 4 + 5 * 8 * 16 + 7 * 16 + 8 * 20 + 16), 2 * (6 * 8 * 16 + 7 * 16 + 2 * 2 * 16)),
+    (128, 5, 10, 0, 4 * 4 + 2 * 4 * 8 + 3 * 8 + 12, None),      # skip layer == last layer: no reverse section
 ])
-def test_packed_layout_size(H, n_lin, multires, prec, expect_frags):
+def test_packed_layout_size(H, n_lin, multires, prec, expect_frags, expect_tfrags):
     L = _lib.lib()
     cfg = _lib.NetConfig(H, n_lin, 4, multires, 1, 0, 1.0)
     n = C.c_size_t()
     assert L.emap_packed_bytes(C.byref(cfg), prec, C.byref(n)) == 0
     hdr = ((2 * n_lin * H * 4 + 1023) // 1024) * 1024
-    assert n.value == hdr + expect_frags * 1024
+    expect = hdr + expect_frags * 1024
+    if expect_tfrags is not None:
+        expect += ((H * 4 + 1023) // 1024) * 1024 + expect_tfrags * 1024   # last layer's fp32 row + transposed fragments
+    assert n.value == expect
 
 
 @pytest.mark.parametrize("m", [1, 2, 3, 8, 10, 12, 16, 32, 50, 64, 127, 128])
