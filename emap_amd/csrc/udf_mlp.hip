@@ -280,7 +280,7 @@ static int mlp_variant(const NetLayout& L, int prec, int64_t P, bool grad) {
     // reverse mode halves the MFMA work of a grad launch but a tile is two dependent sweeps: it wins once every CU has a
     // workgroup (measured crossover between 8k and 32k points).  bf16x3 stays on the forward-mode kernel: its reverse
     // instantiation is not run-to-run deterministic with two workgroups per CU (open issue, DESIGN.md par. 3.1).
-    if (grad && L.has_rev && forced < 0 && grad_mode != 0 && prec != EMAP_PREC_BF16X3 && (P >= 16384 || grad_mode == 1)) return 3;
+    if (grad && L.has_rev && forced < 0 && grad_mode != 0 && (prec != EMAP_PREC_BF16X3 || grad_mode == 1) && (P >= 16384 || grad_mode == 1)) return 3;
     if (forced >= 0) return forced;
     (void)prec; (void)P;
     return 2;   // fs2 (two or three workgroups per CU) measured fastest or equal at every size and mode on MI355X
