@@ -150,6 +150,29 @@ def test_reverse_mode_gradient(name, scale):
         assert rel(ub[:2048], ur) <= tu and rel(gb[:2048], gr) <= tg, prec
 
 
+@pytest.mark.parametrize("ut", ["abs", "square", "sdf"])
+def test_reverse_mode_udf_types_and_narrow_network(ut):
+    """udf_type post-processing (udf_model.py:112-116: abs / square / identity, and its factor on the gradient) in the
+    reverse-sweep kernel, on the default network and on a d_hidden=128 network whose skip layer is not the last one
+    (so the reverse topology exists): reverse mode on 18000 points vs forward mode on the first 4096 of them + oracle."""
+    from emap_amd import synthetic
+    for kw, seed in ((NETS["d8w256L10"][0], 42), (dict(d_in=3, d_out=1, d_hidden=128, n_layers=6, skip_in=(3,), multires=8, bias=0.5), 7)):
+        state = synthetic.make_udf_state(seed=seed, pert=0.02, **kw)
+        net = emap_amd.UDFNetwork(udf_type=ut, precision="f16x3", **kw)
+        net.load_state_dict(state)
+        net = net.to(DEV)
+        gen = torch.Generator().manual_seed(3)
+        x = (torch.rand(18000, 3, generator=gen) * 2 - 1).to(DEV)
+        with torch.no_grad():
+            u, g = net.hip_udf(x, with_grad=True)
+            us, gs = net.hip_udf(x[:4096], with_grad=True)
+        assert rel(u[:4096], us) <= 2e-6 and rel(g[:4096], gs) <= 5e-5, (ut, kw["d_hidden"])
+        cfg = O.UDFConfig(d_hidden=kw["d_hidden"], n_layers=kw["n_layers"], multires=kw["multires"], udf_type=ut,
+                          skip_in=tuple(kw["skip_in"]))
+        ur, gr = O.udf_value_and_grad(state, cfg, x[:1024].cpu())
+        assert rel(u[:1024], ur) <= 1e-4 and rel(g[:1024], gr) <= 1e-4, (ut, kw["d_hidden"])
+
+
 @pytest.mark.parametrize("P", [8192, 32768, 70000])
 def test_mlp_all_tile_geometries_agree(P):
     """The launcher picks the tile geometry from P; all geometries must give the same numbers (bf16 and bf16x3)."""
