@@ -259,6 +259,12 @@ int emap_render_fwd(const EmapNetConfig* cfg, const void* packed, int prec, cons
                             partials, err_flags, st);
 }
 
+int emap_null_direction(const float* grads, int64_t n, int k, float* dir, void* stream) {
+    if (n < 0) { set_error("null_direction: negative n"); return EMAP_E_INVALID; }
+    if (n > 0 && (!grads || !dir)) { set_error("null_direction: null pointer"); return EMAP_E_INVALID; }
+    return launch_null_direction(grads, n, k, dir, static_cast<hipStream_t>(stream));
+}
+
 int emap_profile_enable(int on) {
     if (on && !g_prof_init) {
         for (int i = 0; i < PROF_MAX; ++i)

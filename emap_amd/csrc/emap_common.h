@@ -76,6 +76,8 @@ struct PointSource {
 // temporary is allocated for the launch)
 int launch_mlp(const NetLayout& L, const void* packed, int prec, const PointSource& src, int64_t P,
                float* udf, float* grad3, hipStream_t st, int32_t* err_flags = nullptr, void* scratch = nullptr);
+int launch_null_direction(const float* g, int64_t n, int k, float* dir, hipStream_t st);
+
 constexpr int REV_MAX_WG = 768;      // persistent workgroups of the reverse-mode kernel (3 per CU)
 inline size_t rev_scratch_bytes(const NetLayout& L) {   // sigmoid stash: [workgroup][layer][pair][4][64 lanes x 16 B]
     return L.has_rev ? (size_t)REV_MAX_WG * (size_t)(L.n_lin - 1) * (size_t)(L.H / 32) * 4096 : 0;

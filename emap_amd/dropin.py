@@ -30,4 +30,14 @@ def install(force: bool = True):
             mod = importlib.import_module(real)
             sys.modules[alias] = mod
             setattr(sys.modules["src.models"], alias.rsplit(".", 1)[1], mod)
+    # extraction queries (SURVEY par. 8 f2): the reference module keeps its other functions; only the two query routines
+    # are replaced, and only if the module can be imported at all (it needs nothing but torch)
+    try:
+        ep = importlib.import_module("src.edge_extraction.extract_pointcloud")
+    except Exception:
+        ep = None
+    if ep is not None:
+        from . import extraction
+        ep.get_udf_normals_grid = extraction.get_udf_normals_grid
+        ep.get_udf_normals_slow = extraction.get_udf_normals_slow
     return sorted(_ALIASES)

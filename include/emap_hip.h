@@ -179,6 +179,13 @@ int emap_render_fwd(const EmapNetConfig* cfg, const void* packed, int prec, cons
                     const EmapCompositeOut* out, void* workspace, size_t workspace_bytes, int32_t* err_flags,
                     void* stream);
 
+/* ---- dense-grid extraction (SURVEY par. 8 f2) ----------------------------------------------------
+ * emap_null_direction : `_, _, vh = torch.linalg.svd(grad_ld); F.normalize(vh[:, -1, :])` of get_udf_normals_grid /
+ *                       get_udf_normals_slow (src/edge_extraction/extract_pointcloud.py:86-88, 177-179): per point the unit
+ *                       right singular vector of the smallest singular value of its (k x 3) gradient matrix
+ *                       grads (n, k, 3) -> dir (n, 3); the sign is arbitrary, as in the reference */
+int emap_null_direction(const float* grads, int64_t n, int k, float* dir, void* stream);
+
 /* ---- measurement ----------------------------------------------------------------------------
  * While enabled, emap_render_fwd brackets its dominant kernel (the final value+gradient MLP pass) with
  * hipEvents on the launch stream; emap_profile_read (after the caller synchronised) returns the summed

@@ -296,8 +296,38 @@ def g9_seeded_init():
     save("g9_seeded_init", **out)
 
 
+def g10_extraction():
+    """Dense-grid extraction queries (SURVEY par. 8 f2): the reference's get_udf_normals_grid on a 12^3 grid and
+    get_udf_normals_slow on 300 points, with the reference UDFNetwork on the CPU.  The jitter draws are recorded (they are
+    inputs for the parity tests); get_udf_normals_slow hard-codes ``.cuda()``, which is patched to the identity here."""
+    from src.edge_extraction.extract_pointcloud import get_udf_normals_grid, get_udf_normals_slow  # reference
+    net, state = build_net("d8w256L10")
+    N = 12
+    torch.manual_seed(99)
+    with capture("randn") as noise:
+        df0, _, _, _, _ = get_udf_normals_grid(net.udf, net.gradient, N, -1.0, False, device="cpu")
+        thr = float(df0.reshape(-1).quantile(0.35))
+        df, ld, vecs, samples, vs = get_udf_normals_grid(net.udf, net.gradient, N, thr, True, sampling_N=50, sampling_delta=0.005,
+                                                         max_batch=256, device="cpu")
+    out = dict(N=np.array(N), thr=np.array(thr, dtype=np.float64), df=df, ld=ld, vecs=vecs, voxel_size=vs,
+               grid_noise=torch.cat(list(noise)), state_checksum=state_checksum(state))
+    gen = torch.Generator().manual_seed(5)
+    xyz = (torch.rand(300, 3, generator=gen) * 1.6 - 0.8)
+    orig_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        with capture("randn") as noise2:
+            dfs, normals, lds, _ = get_udf_normals_slow(net.udf, net.gradient, None, xyz, True, sampling_N=50, sampling_delta=0.005,
+                                                        max_batch=128, device="cpu")
+    finally:
+        torch.Tensor.cuda = orig_cuda
+    out.update(xyz=xyz, slow_df=dfs, slow_normals=normals, slow_ld=lds, slow_noise=torch.cat(list(noise2)))
+    save("g10_extraction", **out)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
-    for fn in (g1_pe, g2_mlp, g3_sample_pdf, g4_upsample_step, g5_render, g6_training, g7_perturb, g8_scalars, g9_seeded_init):
+    for fn in (g1_pe, g2_mlp, g3_sample_pdf, g4_upsample_step, g5_render, g6_training, g7_perturb, g8_scalars, g9_seeded_init,
+               g10_extraction):
         if not only or fn.__name__ in only:
             fn()

@@ -241,3 +241,19 @@ def test_interim_backward_matches_reference_gradients(ci):
         ref = t(g["grad." + k])
         got = p.grad if p.grad is not None else torch.zeros(1)
         assert float((got - ref).abs().max()) <= 1e-4 * float(ref.abs().max()) + 1e-8, k
+
+
+def test_extraction_is_gpu_only():
+    """emap_amd.extraction mirrors get_udf_normals_grid / get_udf_normals_slow (extract_pointcloud.py:5-193) and has no CPU
+    fallback: asking for the CPU, or handing CPU tensors to the HIP entry point, fails loudly."""
+    import inspect
+    from emap_amd import extraction
+    sig = inspect.signature(extraction.get_udf_normals_grid)
+    assert list(sig.parameters)[:9] == ["func", "func_grad", "N", "udf_threshold", "is_linedirection", "sampling_N",
+                                        "sampling_delta", "max_batch", "device"]
+    assert list(inspect.signature(extraction.get_udf_normals_slow).parameters)[:9] == [
+        "func", "func_grad", "voxel_size", "xyz", "is_linedirection", "sampling_N", "sampling_delta", "max_batch", "device"]
+    with pytest.raises(RuntimeError):
+        extraction.get_udf_normals_grid(None, None, 4, 0.1, device="cpu")
+    with pytest.raises(RuntimeError):
+        extraction.null_direction(torch.zeros(4, 50, 3))

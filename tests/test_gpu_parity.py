@@ -499,3 +499,97 @@ def test_training_step_gradients_vs_reference_golden():
     cos = float((ours * ref).sum() / (ours.norm() * ref.norm()))
     assert cos >= 0.98, cos
     assert float(ours.norm() / ref.norm()) == pytest.approx(1.0, abs=0.1)
+
+
+# ---------------------------------------------------------------------------------------- extraction queries (par. 8 f2)
+def _dir_err_each(a, b):
+    return 1.0 - (a * b).sum(-1).abs()
+
+
+@pytest.mark.gpu
+def test_null_direction_kernel_vs_svd():
+    """emap_null_direction == F.normalize(torch.linalg.svd(G)[2][:, -1]) (extract_pointcloud.py:86-88) up to sign, against a
+    float64 SVD: random matrices, nearly rank-1 matrices (the real case: 50 almost parallel gradients), k = 1, 2, 50, 128,
+    exact rank deficiency (any unit vector of the null space) and the all-zero matrix (a unit vector, as with LAPACK's vh = I)."""
+    from emap_amd.extraction import null_direction
+    gen = torch.Generator().manual_seed(0)
+    for k in (3, 50, 128):
+        G = torch.randn(1000, k, 3, generator=gen)
+        base = torch.nn.functional.normalize(torch.randn(1000, 1, 3, generator=gen), dim=-1) * 20.0
+        G2 = base + 0.05 * torch.randn(1000, k, 3, generator=gen)                      # nearly rank 1
+        for M in (G, G2):
+            ref = torch.nn.functional.normalize(torch.linalg.svd(M.double())[2][:, -1, :], dim=1).float()
+            s = torch.linalg.svdvals(M.double())
+            ok = (s[:, 1] - s[:, 2]) > 1e-2 * s[:, 1]                                     # the two small singular values differ
+            out = null_direction(M.to(DEV)).cpu()
+            assert float((out.norm(dim=1) - 1).abs().max()) <= 1e-5
+            assert int(ok.sum()) >= 900 and float(_dir_err_each(out, ref)[ok].max()) <= 1e-5, k
+    # k < 3: the null space is at least one-dimensional; any unit vector orthogonal to the rows is right
+    for k in (1, 2):
+        M = torch.randn(64, k, 3, generator=gen)
+        out = null_direction(M.to(DEV)).cpu()
+        assert float((M @ out.unsqueeze(-1)).abs().max()) <= 1e-4 and float((out.norm(dim=1) - 1).abs().max()) <= 1e-5
+    z = null_direction(torch.zeros(5, 50, 3, device=DEV)).cpu()       # LAPACK's vh is the identity here: some unit vector
+    assert float((z.norm(dim=1) - 1).abs().max()) <= 1e-6
+    assert null_direction(torch.zeros(0, 50, 3, device=DEV)).shape == (0, 3)
+
+
+@pytest.mark.gpu
+def test_extraction_points_vs_reference_golden():
+    """get_udf_normals_slow (extract_pointcloud.py:98-193) through emap_amd.extraction with the reference's recorded jitter:
+    values, normals and line directions against the reference's own outputs."""
+    from emap_amd.extraction import get_udf_normals_slow
+    g = load_golden("g10_extraction")
+    net, state, cfg = mk("d8w256L10", "f16x3")
+    df, normals, ld, samples = get_udf_normals_slow(net.udf, net.gradient, None, t(g["xyz"]), True, sampling_N=50,
+                                                    sampling_delta=0.005, max_batch=128, device=DEV, noise=t(g["slow_noise"]))
+    assert samples.shape == (300, 13)
+    assert rel(df, t(g["slow_df"])) <= 1e-4
+    assert float((normals.cpu() - t(g["slow_normals"])).abs().max()) <= 2e-4
+    # line directions: compare where the reference's own direction is well conditioned (oracle singular values)
+    ld_pts = (t(g["xyz"]).unsqueeze(1) + 0.005 * t(g["slow_noise"])).reshape(-1, 3)
+    gr = O.udf_gradient_autograd(state, cfg, ld_pts)[:, 0].reshape(300, 50, 3)
+    s = torch.linalg.svdvals(gr.double())
+    ok = ((s[:, 1] - s[:, 2]) / s[:, 0] > 1e-3)
+    assert int(ok.sum()) >= 150
+    assert float(_dir_err_each(ld.cpu(), t(g["slow_ld"]))[ok].max()) <= 2e-3
+
+
+@pytest.mark.gpu
+def test_extraction_grid_vs_reference_golden():
+    """get_udf_normals_grid (extract_pointcloud.py:5-95) on the reference's 12^3 case; also the generic path (callables that
+    are not this package's UDFNetwork methods) must give the same answer as the batched fast path."""
+    from emap_amd.extraction import get_udf_normals_grid
+    g = load_golden("g10_extraction")
+    net, state, cfg = mk("d8w256L10", "f16x3")
+    N, thr = int(g["N"]), float(g["thr"])
+    gdf = t(g["df"]).reshape(-1)
+    gmask = gdf < thr
+    df0 = get_udf_normals_grid(net.udf, net.gradient, N, -1.0, False, device=DEV)[0].reshape(-1).cpu()
+    assert rel(df0, gdf) <= 1e-4
+    omask = df0 < thr
+    assert int((omask != gmask).sum()) <= 3                     # only points within 1e-4 of the threshold may flip
+    # jitter rows follow the order of the thresholded points: align the recorded draws with OUR thresholded set
+    row_of = torch.cumsum(gmask.long(), 0) - 1
+    noise = torch.zeros(int(omask.sum()), 50, 3)
+    both = omask & gmask
+    noise[(torch.cumsum(omask.long(), 0) - 1)[both]] = t(g["grid_noise"])[row_of[both]]
+    df, ld, vecs, samples, vs = get_udf_normals_grid(net.udf, net.gradient, N, thr, True, sampling_N=50, sampling_delta=0.005,
+                                                     max_batch=256, device=DEV, noise=noise)
+    assert df.shape == (N, N, N) and ld.shape == (N, N, N, 3) and vecs.shape == (N, N, N, 3) and samples.shape == (N ** 3, 12)
+    assert float(vs) == float(g["voxel_size"])
+    v, gv = vecs.reshape(-1, 3).cpu()[both], t(g["vecs"]).reshape(-1, 3)[both]
+    assert float((v != gv).float().mean()) <= 0.01              # -sign(grad) per component (the reference's dim=1 quirk)
+    sub = samples[:, :3].cpu()[both]
+    ld_pts = (sub.unsqueeze(1) + 0.005 * t(g["grid_noise"])[row_of[both]]).reshape(-1, 3)
+    gr = O.udf_gradient_autograd(state, cfg, ld_pts)[:, 0].reshape(-1, 50, 3)
+    s = torch.linalg.svdvals(gr.double())
+    ok = ((s[:, 1] - s[:, 2]) / s[:, 0] > 1e-3)
+    assert int(ok.sum()) >= 100
+    assert float(_dir_err_each(ld.reshape(-1, 3).cpu()[both], t(g["ld"]).reshape(-1, 3)[both])[ok].max()) <= 2e-3
+    assert float(ld.reshape(-1, 3).cpu()[~omask].abs().max()) == 0.0
+    # generic path: wrap the callables so that the fast path is not taken
+    df2, ld2, vecs2, _, _ = get_udf_normals_grid(lambda p: net.udf(p), lambda p: net.gradient(p), N, thr, True, sampling_N=50,
+                                                 sampling_delta=0.005, max_batch=256, device=DEV, noise=noise)
+    assert rel(df2, df) <= 2e-6 and float((vecs2 != vecs).float().mean()) <= 0.01
+    assert float(_dir_err_each(ld2.reshape(-1, 3).cpu()[both], ld.reshape(-1, 3).cpu()[both])[ok].max()) <= 2e-3
