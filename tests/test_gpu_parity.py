@@ -593,3 +593,38 @@ def test_extraction_grid_vs_reference_golden():
                                                  sampling_delta=0.005, max_batch=256, device=DEV, noise=noise)
     assert rel(df2, df) <= 2e-6 and float((vecs2 != vecs).float().mean()) <= 0.01
     assert float(_dir_err_each(ld2.reshape(-1, 3).cpu()[both], ld.reshape(-1, 3).cpu()[both])[ok].max()) <= 2e-3
+
+
+# ---------------------------------------------------------------------------------------- full-image path (par. 8 f4)
+def test_image_render_is_chunk_invariant():
+    """emap_amd.validation.render_image (the render loop of Runner_UDF.validate, runner_udf.py:297-407): rays are
+    independent, so one launch of all rays must equal the reference's schedule of batch_size chunks - with the reference's
+    per-chunk jitter draws (same CPU generator sequence).  Different launch sizes run different MLP kernel geometries
+    (forward-mode / reverse-sweep, 4/8 waves), so the comparison is to the render tolerances, not bit-exact."""
+    from emap_amd.validation import render_image, to_images
+    from emap_amd import synthetic
+    net, _, _ = mk("d8w256L10", "f16x3")
+    r = mk_renderer(net, 64, 64, 4)
+    H, W = 40, 50
+    ro, rd, near, far, ds = synthetic.make_rays(H * W, seed=3)
+    ro, rd, ds = ro.to(DEV), rd.to(DEV), ds.to(DEV)
+    near_f, far_f = float(near.reshape(-1)[0]), float(far.reshape(-1)[0])
+    for perturb in (0.0, 1.0):
+        r.perturb = perturb
+        torch.manual_seed(77)
+        big = render_image(r, ro.reshape(H, W, 3), rd.reshape(H, W, 3), near_f, far_f, ds.reshape(H, W, 1), batch_size=512,
+                           cos_anneal_ratio=1.0, launch_rays=4096)
+        torch.manual_seed(77)
+        ref_e, ref_d, ref_n = [], [], []
+        for h in range(0, H * W, 512):                       # the reference's loop: one render() per batch_size chunk
+            with torch.no_grad():
+                o = r.render(ro[h:h + 512], rd[h:h + 512], near_f, far_f, depth_scale=ds[h:h + 512], cos_anneal_ratio=1.0)
+            ref_e.append(o["edge"]); ref_d.append(o["depth"])
+            S = r.n_samples + r.n_importance
+            ref_n.append((o["gradients_flip"] * o["weights"][:, :S, None]).sum(dim=1))   # runner_udf.py:375-388
+        assert big["edge"].shape == (H * W, 1) and big["normals"].shape == (H * W, 3)
+        assert rel(t(big["edge"]), torch.cat(ref_e)) <= 2e-4, perturb
+        assert rel(t(big["depth"]), torch.cat(ref_d)) <= 5e-4, perturb
+        assert rel(t(big["normals"]), torch.cat(ref_n)) <= 5e-4, perturb
+    e, d, nrm = to_images(big, H, W)
+    assert e.shape == (H, W) and e.dtype.name == "uint8" and d.shape == (H, W) and nrm.shape == (H, W, 3)
