@@ -158,8 +158,8 @@ def main():
         # dominant kernel: the value+grad MLP launch over rays*S points; algorithmic work = value +
         # reverse-mode input gradient = 2F per point (SURVEY par. 8d)
         flops_launch = a.rays * S * 2 * F_POINT
-        # udf_mlp.hip:mlp_variant: reverse-sweep kernel for grad launches of >= 16384 points (not bf16x3), else forward mode
-        dominant_kernel = (f"udf_mlp_rev_kernel<256,{a.precision}>" if (a.rays * S >= 16384 and a.precision != "bf16x3")
+        # udf_mlp.hip:mlp_variant: reverse-sweep kernel for grad launches of >= 10240 (f16x3) / 16384 (single-pass) points, not bf16x3
+        dominant_kernel = (f"udf_mlp_rev_kernel<256,{a.precision}>" if (a.rays * S >= (10240 if a.precision == "f16x3" else 16384) and a.precision != "bf16x3")
                            else f"udf_mlp_fs2_kernel<256,{a.precision},4,grad>")
         ach = flops_launch / k_avg_s / 1e12 if k_avg_s > 0 else 0.0
         line = {
