@@ -155,6 +155,25 @@ def test_reverse_mode_gradient(name, scale):
         assert rel(ub[:2048], ur) <= tu and rel(gb[:2048], gr) <= tg, prec
 
 
+@pytest.mark.parametrize("P", [10240, 10241, 10303, 16384, 16385, 32768 + 63])
+def test_reverse_mode_ragged_sizes_vs_oracle(P):
+    """Sizes at and just above the forward/reverse switch-over and with ragged last tiles (64-point tiles): first and last
+    300 points against the oracle, in the parity mode and (from 16384 points) in a single-pass mode."""
+    net, state, cfg = mk("d8w256L10", "f16x3")
+    gen = torch.Generator().manual_seed(P)
+    x = (torch.rand(P, 3, generator=gen) * 2 - 1)
+    with torch.no_grad():
+        u, g = net.hip_udf(x.to(DEV), with_grad=True)
+    sel = torch.cat([torch.arange(300), torch.arange(P - 300, P)])
+    ur, gr = O.udf_value_and_grad(state, cfg, x[sel])
+    assert rel(u.cpu()[sel], ur) <= 1e-4 and rel(g.cpu()[sel], gr) <= 1e-4
+    if P >= 16384:
+        nb, _, _ = mk("d8w256L10", "f16")
+        with torch.no_grad():
+            ub, gb = nb.hip_udf(x.to(DEV), with_grad=True)
+        assert rel(ub.cpu()[sel], ur) <= 3e-3 and rel(gb.cpu()[sel], gr) <= 1e-2
+
+
 @pytest.mark.parametrize("ut", ["abs", "square", "sdf"])
 def test_reverse_mode_udf_types_and_narrow_network(ut):
     """udf_type post-processing (udf_model.py:112-116: abs / square / identity, and its factor on the gradient) in the
