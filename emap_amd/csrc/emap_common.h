@@ -5,7 +5,19 @@
 #include <stdio.h>
 #include "../../include/emap_hip.h"
 
+// split-fp16 ("f16x3") arithmetic with ONE accumulator: instead of storing the lo parts x2^11 (f16 subnormals are flushed by the
+// MFMA) and keeping the lo x hi products in a second accumulator, BOTH operands are pre-scaled - weights by F16X3_WS at pack
+// time, activations by a per-kernel power of two - so that hi and lo parts are normal numbers and all three products land in
+// one accumulator at scale WS*XS (undone in the epilogue).  Weights |w| <= 0.5, activations and deltas <= O(1), forward-mode
+// tangents <= O(1e3) on the reference networks: 2^13 * 0.5, 2^9 * 64 and 2^4 * 4e3 stay below the f16 maximum.
+// Measured (round 1): same accuracy (udf 6e-7, grad 1e-5 / 1e-6), all parity tests green, but 3 % SLOWER than the
+// two-accumulator form (the extra scaling multiplies cost more than the freed registers buy), so it is off by default.
+#ifndef EMAP_F16X3_ONE_ACC
+#define EMAP_F16X3_ONE_ACC 0
+#endif
+
 namespace emap {
+constexpr float F16X3_WS = 8192.0f;
 
 // ---- error plumbing (host) ------------------------------------------------------------------
 void set_error(const char* fmt, ...);

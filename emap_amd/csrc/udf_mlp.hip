@@ -98,8 +98,14 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackArgs a) {
         if (o < Ld.out_dim && col >= 0 && col < n_in) w = rs[l * H + o] * a.v[l][(size_t)o * n_in + col] * mult;
         const __bf16 hi = (__bf16)w;
         outv[e] = (part == 0) ? hi : (__bf16)(w - (float)hi);
+#if EMAP_F16X3_ONE_ACC
+        const float ws = (NP == 2) ? w * F16X3_WS : w;                        // split-fp16: pre-scaled weights, plain lo part
+        const _Float16 hh = (_Float16)ws;
+        outh[e] = (part == 0) ? hh : (_Float16)(ws - (float)hh);
+#else
         const _Float16 hh = (_Float16)w;
         outh[e] = (part == 0) ? hh : (_Float16)((w - (float)hh) * 2048.0f);  // lo parts scaled by 2^11 (split-fp16)
+#endif
     }
     char* dst = a.packed + a.L.frag_off_bytes + F * FRAG_BYTES + lane * 16;
     if (f16) *reinterpret_cast<f16x8*>(dst) = outh;
@@ -169,8 +175,14 @@ __global__ __launch_bounds__(256) void pack_t_kernel(const PackArgs a) {
         if (o < Ld.out_dim && col >= 0 && col < n_in) w = rs[l * H + o] * a.v[l][(size_t)o * n_in + col] * mult;
         const __bf16 hi = (__bf16)w;
         outv[e] = (part == 0) ? hi : (__bf16)(w - (float)hi);
+#if EMAP_F16X3_ONE_ACC
+        const float ws = (NP == 2) ? w * F16X3_WS : w;
+        const _Float16 hh = (_Float16)ws;
+        outh[e] = (part == 0) ? hh : (_Float16)(ws - (float)hh);
+#else
         const _Float16 hh = (_Float16)w;
         outh[e] = (part == 0) ? hh : (_Float16)((w - (float)hh) * 2048.0f);
+#endif
     }
     char* dst = a.packed + a.L.t_frag_off_bytes + F * FRAG_BYTES + lane * 16;
     if (f16) *reinterpret_cast<f16x8*>(dst) = outh;
