@@ -21,6 +21,7 @@ PREC_F16X3 = 3
 PRECISIONS = {"bf16": PREC_BF16, "bf16x3": PREC_BF16X3, "f16": PREC_F16, "f16x3": PREC_F16X3}
 UDF_TYPES = {"abs": 0, "square": 1, "sdf": 2}
 MAX_LIN = 12
+ABI_VERSION = 2
 
 F_NAN_SAMPLES = 1
 F_NAN_GRADERR = 2
@@ -47,6 +48,18 @@ class RenderParams(C.Structure):
                 ("gamma_dev", C.c_void_p), ("beta_min", C.c_float), ("reserved", C.c_int32)]
 
 
+class CompositeGrads(C.Structure):
+    _fields_ = [("d_edge", C.c_void_p), ("d_depth", C.c_void_p), ("d_gradient_error", C.c_void_p),
+                ("d_gradient_error_near_surface", C.c_void_p), ("scalars", C.c_void_p), ("d_variance", C.c_void_p),
+                ("d_beta", C.c_void_p), ("d_gamma", C.c_void_p), ("grad_scale", C.c_float), ("accumulate", C.c_int32)]
+
+
+class ParamGrads(C.Structure):
+    _fields_ = [("g_host", C.POINTER(C.c_void_p)), ("v_host", C.POINTER(C.c_void_p)), ("dg_host", C.POINTER(C.c_void_p)),
+                ("dv_host", C.POINTER(C.c_void_p)), ("db_host", C.POINTER(C.c_void_p)), ("weight_norm", C.c_int32),
+                ("accumulate", C.c_int32), ("grad_scale", C.c_float), ("reserved", C.c_int32)]
+
+
 # every symbol include/emap_hip.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
 SYMBOLS = {
@@ -55,7 +68,8 @@ SYMBOLS = {
     "emap_packed_bytes": (C.c_int, [C.POINTER(NetConfig), C.c_int, C.POINTER(C.c_size_t)]),
     "emap_pack_weights": (C.c_int, [C.POINTER(NetConfig), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), _P, C.c_int, _P]),
     "emap_udf_fwd": (C.c_int, [C.POINTER(NetConfig), _P, C.c_int, _P, C.c_int64, _P, _P]),
-    "emap_udf_fwd_grad": (C.c_int, [C.POINTER(NetConfig), _P, C.c_int, _P, C.c_int64, _P, _P, _P]),
+    "emap_udf_scratch_bytes": (C.c_int, [C.POINTER(NetConfig), C.c_int, C.c_int64, C.POINTER(C.c_size_t)]),
+    "emap_udf_fwd_grad": (C.c_int, [C.POINTER(NetConfig), _P, C.c_int, _P, C.c_int64, _P, _P, _P, C.c_size_t, _P]),
     "emap_embed": (C.c_int, [_P, C.c_int64, C.c_int, _P, _P]),
     "emap_null_direction": (C.c_int, [_P, C.c_int64, C.c_int, _P, _P]),
     "emap_sample_pdf": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
@@ -67,9 +81,17 @@ SYMBOLS = {
                                      C.POINTER(CompositeOut), _P, _P, _P]),
     "emap_composite_fwd_p": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, _P, C.POINTER(RenderParams),
                                        C.POINTER(CompositeOut), _P, _P, _P]),
-    "emap_render_workspace_bytes": (C.c_int, [C.POINTER(RenderParams), C.POINTER(C.c_size_t)]),
+    "emap_render_workspace_bytes": (C.c_int, [C.POINTER(NetConfig), C.c_int, C.POINTER(RenderParams), C.POINTER(C.c_size_t)]),
     "emap_render_fwd": (C.c_int, [C.POINTER(NetConfig), _P, C.c_int, C.POINTER(RenderParams), _P, _P, _P, _P, _P, _P,
                                   _P, _P, _P, C.POINTER(CompositeOut), _P, C.c_size_t, _P, _P]),
+    "emap_composite_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, _P, C.POINTER(RenderParams),
+                                     C.POINTER(CompositeGrads), _P, _P, _P, _P]),
+    "emap_udf_vjp_workspace_bytes": (C.c_int, [C.POINTER(NetConfig), C.c_int, C.c_int64, C.POINTER(C.c_size_t)]),
+    "emap_udf_vjp": (C.c_int, [C.POINTER(NetConfig), _P, C.c_int, _P, C.c_int64, _P, _P, C.POINTER(ParamGrads), _P, C.c_size_t,
+                               _P, _P]),
+    "emap_render_bwd_workspace_bytes": (C.c_int, [C.POINTER(NetConfig), C.c_int, C.POINTER(RenderParams), C.POINTER(C.c_size_t)]),
+    "emap_render_bwd": (C.c_int, [C.POINTER(NetConfig), _P, C.c_int, C.POINTER(RenderParams), _P, _P, _P, _P, _P, _P, _P,
+                                  C.POINTER(CompositeGrads), C.POINTER(ParamGrads), _P, C.c_size_t, _P, _P]),
     "emap_profile_enable": (C.c_int, [C.c_int]),
     "emap_profile_read": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "emap_linspace_host": (None, [C.c_float, C.c_float, C.c_int, C.POINTER(C.c_float)]),
@@ -103,7 +125,7 @@ def lib():
             raise EmapLibraryError(f"{LIB_PATH} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
-    if l.emap_abi_version() != 1:
+    if l.emap_abi_version() != ABI_VERSION:
         raise EmapLibraryError("libemap_hip.so ABI version mismatch")
     _lib = l
     return l
@@ -126,8 +148,15 @@ def ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
-def stream_ptr():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def stream_ptr(device=None):
+    """Current stream of `device` (default: the current device).  Callers that take tensors from an explicit device wrap the
+    C call in ``torch.cuda.device(t.device)`` and pass ``t.device`` here, so kernels land on the tensor's device and stream."""
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def on_device(t: torch.Tensor):
+    """Context manager: make t's device current for the C call (kernel launches and the per-function LDS attribute are per device)."""
+    return torch.cuda.device(t.device)
 
 
 def f32c(t: torch.Tensor) -> torch.Tensor:

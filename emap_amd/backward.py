@@ -1,0 +1,174 @@
+"""Training backward of the render hot path, evaluated by libemap_hip (SURVEY.md par. 8 f1).
+
+What the reference gets from ``loss.backward()`` (reference src/runner/runner_udf.py:166-167) is autograd through
+``render_core`` and ``UDFNetwork.gradient(create_graph=True)`` (src/models/udf_renderer_blending.py:457-625,
+src/models/udf_model.py:121-135).  Here two ``torch.autograd.Function`` objects hand that job to the HIP kernels:
+
+``RenderFn``   forward = ``emap_render_fwd`` (the whole render), backward = ``emap_render_bwd``
+               (composite_bwd -> udf_mlp_vjp sweep -> weight-gradient GEMMs -> reduction + weight-norm VJP).
+``UdfFn``      forward = ``emap_udf_fwd[_grad]``, backward = ``emap_udf_vjp`` - for direct calls of
+               ``UDFNetwork.forward/udf/gradient`` with trainable parameters.
+
+Parameter gradients are written by the kernels into ONE flat fp32 buffer laid out in ``parameters()`` order and returned
+to autograd as views of it (a data-parallel caller all-reduces that buffer as it is, emap_amd/parallel.py).
+There is no PyTorch fallback: a loss that depends on a render output whose gradient the kernels do not provide raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional
+
+import torch
+
+from . import _lib
+
+
+class ParamLayout:
+    """Flat layout of the trainable tensors of (UDFNetwork, variance, beta, gamma) and the pointer tables the C ABI takes."""
+
+    def __init__(self, net, deviation_network=None, beta_network=None):
+        self.net = net
+        gs, vs, bs = net._gvb()
+        self.n_lin = len(vs)
+        self.weight_norm = bool(net.weight_norm)
+        order = list(net.parameters())
+        self.extra = []
+        if deviation_network is not None:
+            self.extra = [deviation_network.variance, beta_network.beta, beta_network.gamma]
+        self.tensors: List[torch.Tensor] = order + self.extra
+        self.offsets = {}
+        off = 0
+        for p in self.tensors:
+            self.offsets[id(p)] = off
+            off += p.numel()
+        self.numel = off
+        self.gs, self.vs, self.bs = gs, vs, bs
+
+    def tables(self, flat: torch.Tensor):
+        """(ParamGrads struct, keep-alive list) with the d* tables pointing into `flat`."""
+        n = self.n_lin
+        es = flat.element_size()
+        base = flat.data_ptr()
+
+        def arr(ts, grad):
+            if grad:
+                return (C.c_void_p * n)(*[base + es * self.offsets[id(t)] for t in ts])
+            return (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+
+        pg = _lib.ParamGrads()
+        keep = []
+        v_a, dv_a, db_a = arr(self.vs, False), arr(self.vs, True), arr(self.bs, True)
+        keep += [v_a, dv_a, db_a]
+        pg.v_host, pg.dv_host, pg.db_host = v_a, dv_a, db_a
+        if self.weight_norm:
+            g_a, dg_a = arr(self.gs, False), arr(self.gs, True)
+            keep += [g_a, dg_a]
+            pg.g_host, pg.dg_host = g_a, dg_a
+        pg.weight_norm = int(self.weight_norm)
+        pg.accumulate = 0
+        pg.grad_scale = 1.0
+        return pg, keep
+
+    def check(self):
+        for t in self.vs + self.bs + (self.gs if self.weight_norm else []):
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                raise RuntimeError("emap_amd backward: UDFNetwork parameters must be contiguous fp32")
+
+    def views(self, flat: torch.Tensor, need: List[bool]):
+        out = []
+        for p, nd in zip(self.tensors, need):
+            o = self.offsets[id(p)]
+            out.append(flat[o:o + p.numel()].view(p.shape) if nd else None)
+        return out
+
+
+def _workspace(cache: dict, key, nbytes: int, dev) -> torch.Tensor:
+    ws = cache.get(key)
+    if ws is None or ws.numel() < nbytes or ws.device != dev:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        cache.clear()
+        cache[key] = ws
+    return ws
+
+
+class UdfFn(torch.autograd.Function):
+    """(udf (P,1), grad (P,3) | None) of UDFNetwork at x with HIP forward and HIP parameter gradients."""
+
+    @staticmethod
+    def forward(ctx, net, x, with_grad, *params):
+        udf, grad = net.hip_udf(x, with_grad=with_grad or x.requires_grad)
+        ctx.net = net
+        ctx.with_grad = with_grad
+        ctx.x_needs = x.requires_grad
+        ctx.save_for_backward(x.detach(), grad if x.requires_grad else None)
+        ctx.set_materialize_grads(False)
+        if with_grad:
+            return udf, grad
+        return udf, None
+
+    @staticmethod
+    def backward(ctx, d_udf, d_grad):
+        net = ctx.net
+        x, grad = ctx.saved_tensors
+        lay = ParamLayout(net)
+        lay.check()
+        xs = _lib.f32c(x.reshape(-1, 3))
+        P = xs.shape[0]
+        dev = xs.device
+        du = _lib.f32c(d_udf.reshape(-1)) if d_udf is not None else torch.zeros(P, device=dev)
+        dg = _lib.f32c(d_grad.reshape(-1, 3)) if d_grad is not None else torch.zeros(P, 3, device=dev)
+        if ctx.x_needs and d_grad is not None:
+            raise NotImplementedError("emap_amd: d/dx of grad_x udf (a second-order input gradient) is not provided by the HIP backward")
+        flat = torch.empty(lay.numel, dtype=torch.float32, device=dev)
+        pg, keep = lay.tables(flat)
+        L = _lib.lib()
+        prec = _lib.PRECISIONS[net.precision]
+        cfg = net.net_config()
+        nb = C.c_size_t()
+        with _lib.on_device(xs):
+            _lib.check(L.emap_udf_vjp_workspace_bytes(C.byref(cfg), prec, P, C.byref(nb)), "udf_vjp_workspace_bytes")
+            ws = _workspace(net._vjp_ws, ("udf", P), nb.value, dev)
+            _lib.check(L.emap_udf_vjp(C.byref(cfg), _lib.ptr(net.packed()), prec, _lib.ptr(xs), P, _lib.ptr(du), _lib.ptr(dg),
+                                      C.byref(pg), _lib.ptr(ws), ws.numel(), _lib.ptr(net.err_word(dev)), _lib.stream_ptr(dev)),
+                       "udf_vjp")
+        need = [p.requires_grad for p in lay.tensors]
+        dx = None
+        if ctx.x_needs:
+            dx = (du.view(-1, 1) * grad).view(x.shape)   # d udf / dx = grad_x udf
+        return (None, dx, None) + tuple(lay.views(flat, need))
+
+
+class RenderFn(torch.autograd.Function):
+    """render(): forward = emap_render_fwd, backward = emap_render_bwd."""
+
+    DIFF = ("edge", "depth", "gradient_error", "gradient_error_near_surface")
+    # returned through the Function so that a loss which touches them fails loudly instead of silently dropping a term
+    GUARDED = ("udf", "weights", "normals", "gradients", "gradients_flip", "gradient_mag", "weight_sum")
+
+    @staticmethod
+    def forward(ctx, renderer, call, *params):
+        v = renderer._render_hip(call)
+        ctx.renderer = renderer
+        ctx.call = call
+        ctx.v = v
+        call["_v"] = v   # the non-differentiable entries of the dict (masks, z_vals, ...) for render()
+        ctx.set_materialize_grads(False)
+        N, S = call["N"], call["S"]
+        outs = (v["edge"].view(N, 1), v["depth"].view(N, 1), v["scalars"][0], v["scalars"][1],
+                v["udf"].view(N, S), v["weights"].view(N, S), v["normals"].view(N, 3), v["gradients"].view(N, S, 3),
+                v["gradients_flip"].view(N, S, 3), v["gradient_mag"].view(N, S), v["weight_sum"].view(N, 1))
+        return outs
+
+    @staticmethod
+    def backward(ctx, d_edge, d_depth, d_ge, d_ge_ns, *guarded):
+        for k, g in zip(RenderFn.GUARDED, guarded):
+            if g is not None:
+                raise NotImplementedError(
+                    f"emap_amd: the loss depends on render()['{k}'], whose gradient the HIP backward does not provide "
+                    "(differentiable outputs: edge, depth, gradient_error, gradient_error_near_surface, variance, beta, gamma)")
+        r, call, v = ctx.renderer, ctx.call, ctx.v
+        flat = r.backward_into(call, v, d_edge, d_depth, d_ge, d_ge_ns)
+        lay = r._layout()
+        need = [p.requires_grad for p in lay.tensors]
+        ctx.v = None
+        return (None, None) + tuple(lay.views(flat, need))

@@ -39,6 +39,96 @@ int launch_composite(const float*, const float*, const float*, const float*, con
                      const float*, const float*, float, const EmapCompositeOut*, float*, int32_t*, hipStream_t);
 int launch_embed(const float*, int64_t, int, float*, hipStream_t);
 void linspace_host(float, float, int, float*);
+int launch_composite_bwd(const float*, const float*, const float*, const float*, const float*, const float*, int, int,
+                         const float*, const EmapRenderParams*, const EmapCompositeGrads*, float*, float*, float*, uint32_t*,
+                         hipStream_t);
+
+// ---- training backward (udf_mlp_vjp.inc, wgrad.hip) ----
+#define EMAP_VJP_DECL(m) \
+    int launch_vjp_sweep_##m(const NetLayout&, const void*, const PointSource&, int64_t, int, int, const float*, const float*, \
+                             const VjpLayout&, char*, char*, char*, int, const uint32_t*, hipStream_t, int32_t*);
+EMAP_VJP_DECL(bf16) EMAP_VJP_DECL(bf16x3) EMAP_VJP_DECL(f16) EMAP_VJP_DECL(f16x3)
+#undef EMAP_VJP_DECL
+size_t plan_wgrad(const NetLayout&, const VjpLayout&, int, WgradJob*, int*, int*, int*, int*);
+int launch_absmax(const float*, const float*, int64_t, uint32_t*, hipStream_t);
+int launch_wgrad(const NetLayout&, const VjpLayout&, const WgradJob*, int, int, const char*, const char*, float*, int, int,
+                 hipStream_t);
+int launch_wgrad_reduce(const NetLayout&, const WgradJob*, int, const int*, const int*, const float*, const uint32_t*,
+                        const float* const*, const float* const*, float* const*, float* const*, float* const*, int, int, float,
+                        hipStream_t);
+
+static int device_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) n = pr.multiProcessorCount;
+        else n = 256;
+    }
+    return n;
+}
+
+struct VjpPlan {
+    VjpLayout V;
+    WgradJob jobs[WGRAD_MAX_JOBS];
+    int n_jobs, job_h[EMAP_MAX_LIN], job_pe[EMAP_MAX_LIN], wgrad_wg, sweep_grid, chunk_tiles;
+    size_t off_absmax, off_slab, off_partial, off_a, off_z, total;
+};
+
+static VjpPlan plan_vjp(const NetLayout& L, int64_t P) {
+    VjpPlan pl;
+    build_vjp_layout(L, &pl.V);
+    const int cus = device_cus();
+    pl.sweep_grid = (L.H == 256) ? cus : 2 * cus;          // 8 waves: one workgroup per CU; 4 waves: two
+    const int64_t tiles = (P + VJP_PT - 1) / VJP_PT;
+    pl.chunk_tiles = (int)std::min<int64_t>(std::max<int64_t>(tiles, 1), VJP_CHUNK_TILES);
+    const size_t pfl = plan_wgrad(L, pl.V, cus, pl.jobs, &pl.n_jobs, pl.job_h, pl.job_pe, &pl.wgrad_wg);
+    size_t off = 0;
+    pl.off_absmax = off; off += 256;
+    pl.off_slab = off; off += (size_t)pl.sweep_grid * pl.V.s_slab_kb * 1024;
+    pl.off_partial = off; off += ((pfl * 4 + 255) & ~(size_t)255);
+    pl.off_a = off; off += (size_t)pl.chunk_tiles * pl.V.a_tile_kb * 1024;
+    pl.off_z = off; off += (size_t)pl.chunk_tiles * pl.V.z_tile_kb * 1024;
+    pl.total = off;
+    return pl;
+}
+
+// d/dtheta of sum_p du[p] udf(x_p) + dg[p] . grad udf(x_p); absmax must already hold max|du|, max|dg| of the launch
+static int run_vjp(const NetLayout& L, const void* packed, int prec, const PointSource& src, int64_t P, const float* d_udf,
+                   const float* d_grad, const EmapParamGrads* out, const VjpPlan& pl, char* ws, int32_t* err, hipStream_t st) {
+    uint32_t* absmax = reinterpret_cast<uint32_t*>(ws + pl.off_absmax);
+    float* partial = reinterpret_cast<float*>(ws + pl.off_partial);
+    const int64_t tiles = (P + VJP_PT - 1) / VJP_PT;
+    int chunk = 0;
+    for (int64_t t0 = 0; t0 < tiles || chunk == 0; t0 += pl.chunk_tiles, ++chunk) {
+        const int nt = (int)std::min<int64_t>(pl.chunk_tiles, std::max<int64_t>(tiles - t0, 0));
+        int rc = EMAP_OK;
+        switch (prec) {
+            case EMAP_PREC_BF16: rc = launch_vjp_sweep_bf16(L, packed, src, P, (int)t0, nt, d_udf, d_grad, pl.V, ws + pl.off_a, ws + pl.off_z, ws + pl.off_slab, pl.sweep_grid, absmax, st, err); break;
+            case EMAP_PREC_BF16X3: rc = launch_vjp_sweep_bf16x3(L, packed, src, P, (int)t0, nt, d_udf, d_grad, pl.V, ws + pl.off_a, ws + pl.off_z, ws + pl.off_slab, pl.sweep_grid, absmax, st, err); break;
+            case EMAP_PREC_F16: rc = launch_vjp_sweep_f16(L, packed, src, P, (int)t0, nt, d_udf, d_grad, pl.V, ws + pl.off_a, ws + pl.off_z, ws + pl.off_slab, pl.sweep_grid, absmax, st, err); break;
+            default: rc = launch_vjp_sweep_f16x3(L, packed, src, P, (int)t0, nt, d_udf, d_grad, pl.V, ws + pl.off_a, ws + pl.off_z, ws + pl.off_slab, pl.sweep_grid, absmax, st, err); break;
+        }
+        if (rc) return rc;
+        rc = launch_wgrad(L, pl.V, pl.jobs, pl.n_jobs, pl.wgrad_wg, ws + pl.off_a, ws + pl.off_z, partial, nt, chunk > 0 ? 1 : 0, st);
+        if (rc) return rc;
+        if (tiles == 0) break;
+    }
+    return launch_wgrad_reduce(L, pl.jobs, pl.n_jobs, pl.job_h, pl.job_pe, partial, absmax, out->g_host, out->v_host, out->dg_host,
+                               out->dv_host, out->db_host, out->weight_norm, out->accumulate, out->grad_scale, st);
+}
+
+static int check_param_grads(const NetLayout& L, const EmapParamGrads* o, const char* who) {
+    if (!o || !o->v_host || !o->dv_host || !o->db_host) { set_error("%s: null parameter-gradient table", who); return EMAP_E_INVALID; }
+    if (o->weight_norm && (!o->g_host || !o->dg_host)) { set_error("%s: weight_norm needs g_host and dg_host", who); return EMAP_E_INVALID; }
+    for (int l = 0; l < L.n_lin; ++l) {
+        if (!o->v_host[l] || !o->dv_host[l] || !o->db_host[l] || (o->weight_norm && (!o->g_host[l] || !o->dg_host[l]))) {
+            set_error("%s: null tensor for layer %d", who, l);
+            return EMAP_E_INVALID;
+        }
+    }
+    return EMAP_OK;
+}
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -52,10 +142,10 @@ static hipEvent_t g_prof_ev[PROF_MAX][2];
 static bool g_prof_init = false;
 
 struct Workspace {
-    size_t sample_dist, z_a, z_b, udf_a, udf_b, z_new, udf_new, partials, total;
+    size_t sample_dist, z_a, z_b, udf_a, udf_b, z_new, udf_new, partials, rev, total;
 };
 
-static Workspace plan_workspace(const EmapRenderParams& p) {
+static Workspace plan_workspace(const EmapRenderParams& p, const NetLayout* L = nullptr) {
     const size_t N = (size_t)std::max(p.n_rays, 0);
     const int m = p.up_sample_steps > 0 ? p.n_importance / p.up_sample_steps : 0;
     const size_t S = (size_t)p.n_samples + (size_t)m * std::max(p.up_sample_steps, 0);
@@ -69,6 +159,7 @@ static Workspace plan_workspace(const EmapRenderParams& p) {
     w.z_new = off; off += align256(N * (size_t)std::max(m, 1) * 4);
     w.udf_new = off; off += align256(N * (size_t)std::max(m, 1) * 4);
     w.partials = off; off += align256(N * 8 * 4);
+    w.rev = off; off += L ? align256(rev_scratch_bytes(*L)) : 0;   // sigma' slabs of the reverse-mode value+gradient kernel
     w.total = off;
     return w;
 }
@@ -103,28 +194,41 @@ int emap_pack_weights(const EmapNetConfig* cfg, const float* const* g, const flo
 }
 
 static int udf_call(const EmapNetConfig* cfg, const void* packed, int prec, const float* x, int64_t P, float* udf,
-                    float* grad3, void* stream) {
+                    float* grad3, void* scratch, size_t scratch_bytes, void* stream) {
     NetLayout L;
     const int rc = build_layout(cfg, prec, &L);
     if (rc) return rc;
     if (!packed || !udf || (P > 0 && !x)) { set_error("udf_fwd: null pointer"); return EMAP_E_INVALID; }
     if (P < 0) { set_error("udf_fwd: negative P"); return EMAP_E_INVALID; }
     if (P == 0) return EMAP_OK;
+    if (grad3 && mlp_uses_rev(L, prec, P) && (!scratch || scratch_bytes < rev_scratch_bytes(L))) {
+        set_error("udf_fwd_grad: scratch %zu < %zu bytes (emap_udf_scratch_bytes)", scratch ? scratch_bytes : (size_t)0, rev_scratch_bytes(L));
+        return EMAP_E_WORKSPACE;
+    }
     PointSource src;
     memset(&src, 0, sizeof(src));
     src.x = x;
-    return launch_mlp(L, packed, prec, src, P, udf, grad3, static_cast<hipStream_t>(stream));
+    return launch_mlp(L, packed, prec, src, P, udf, grad3, static_cast<hipStream_t>(stream), nullptr, scratch);
+}
+
+int emap_udf_scratch_bytes(const EmapNetConfig* cfg, int prec, int64_t P, size_t* bytes) {
+    NetLayout L;
+    const int rc = build_layout(cfg, prec, &L);
+    if (rc) return rc;
+    if (!bytes || P < 0) { set_error("udf_scratch_bytes: bad argument"); return EMAP_E_INVALID; }
+    *bytes = mlp_uses_rev(L, prec, P) ? rev_scratch_bytes(L) : 0;
+    return EMAP_OK;
 }
 
 int emap_udf_fwd(const EmapNetConfig* cfg, const void* packed, int prec, const float* x, int64_t P, float* udf,
                  void* stream) {
-    return udf_call(cfg, packed, prec, x, P, udf, nullptr, stream);
+    return udf_call(cfg, packed, prec, x, P, udf, nullptr, nullptr, 0, stream);
 }
 
 int emap_udf_fwd_grad(const EmapNetConfig* cfg, const void* packed, int prec, const float* x, int64_t P, float* udf,
-                      float* grad3, void* stream) {
+                      float* grad3, void* scratch, size_t scratch_bytes, void* stream) {
     if (!grad3) { set_error("udf_fwd_grad: grad3 is null"); return EMAP_E_INVALID; }
-    return udf_call(cfg, packed, prec, x, P, udf, grad3, stream);
+    return udf_call(cfg, packed, prec, x, P, udf, grad3, scratch, scratch_bytes, stream);
 }
 
 int emap_embed(const float* x, int64_t P, int multires, float* pe, void* stream) {
@@ -174,9 +278,12 @@ int emap_composite_fwd_p(const float* rays_o, const float* rays_d, const float* 
                             partials, err_flags, static_cast<hipStream_t>(stream));
 }
 
-int emap_render_workspace_bytes(const EmapRenderParams* p, size_t* bytes) {
+int emap_render_workspace_bytes(const EmapNetConfig* cfg, int prec, const EmapRenderParams* p, size_t* bytes) {
+    NetLayout L;
+    const int rc = build_layout(cfg, prec, &L);
+    if (rc) return rc;
     if (!p || !bytes) { set_error("render_workspace_bytes: null pointer"); return EMAP_E_INVALID; }
-    *bytes = plan_workspace(*p).total;
+    *bytes = plan_workspace(*p, &L).total;
     return EMAP_OK;
 }
 
@@ -198,7 +305,7 @@ int emap_render_fwd(const EmapNetConfig* cfg, const void* packed, int prec, cons
     const int steps = (m > 0) ? K : 0;
     const int S = Sc + m * steps;
     if (S > 256) { set_error("render_fwd: %d samples per ray exceed the kernel limit of 256", S); return EMAP_E_INVALID; }
-    const Workspace w = plan_workspace(*p);
+    const Workspace w = plan_workspace(*p, &L);
     if (workspace_bytes < w.total) { set_error("render_fwd: workspace %zu < %zu bytes", workspace_bytes, w.total); return EMAP_E_WORKSPACE; }
     char* ws = static_cast<char*>(workspace);
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -250,13 +357,114 @@ int emap_render_fwd(const EmapNetConfig* cfg, const void* packed, int prec, cons
     fin.rays_o = rays_o; fin.rays_d = rays_d; fin.z = z_vals; fin.n_per_ray = S; fin.mid = 1; fin.sample_dist = sample_dist;
     const bool prof = g_prof_on && g_prof_n < PROF_MAX;
     if (prof) (void)hipEventRecord(g_prof_ev[g_prof_n][0], st);
-    rc = launch_mlp(L, packed, prec, fin, (int64_t)N * S, udf, grad3, st, err_flags);
+    rc = launch_mlp(L, packed, prec, fin, (int64_t)N * S, udf, grad3, st, err_flags, ws + w.rev);
     if (prof) { (void)hipEventRecord(g_prof_ev[g_prof_n][1], st); ++g_prof_n; }
     if (rc) return rc;
     return launch_composite(rays_o, rays_d, z_vals, udf, grad3, depth_scale, N, S, sample_dist, p->inv_s, p->beta, p->gamma,
                             p->cos_anneal_ratio, p->has_cos_anneal, p->flip_saturation, p->near_surface, p->sparse_scale,
                             p->background, p->has_background, p->variance_dev, p->beta_dev, p->gamma_dev, p->beta_min, out,
                             partials, err_flags, st);
+}
+
+int emap_composite_bwd(const float* rays_o, const float* rays_d, const float* z, const float* udf, const float* grad3,
+                       const float* depth_scale, int N, int S, const float* sample_dist_dev, const EmapRenderParams* p,
+                       const EmapCompositeGrads* g, float* d_udf, float* d_grad3, float* partials, void* stream) {
+    if (!p || !g || (N > 0 && (!rays_o || !rays_d || !z || !udf || !grad3 || !sample_dist_dev || !d_udf || !d_grad3 || !partials))) {
+        set_error("composite_bwd: null pointer");
+        return EMAP_E_INVALID;
+    }
+    return launch_composite_bwd(rays_o, rays_d, z, udf, grad3, depth_scale, N, S, sample_dist_dev, p, g, d_udf, d_grad3, partials,
+                                nullptr, static_cast<hipStream_t>(stream));
+}
+
+int emap_udf_vjp_workspace_bytes(const EmapNetConfig* cfg, int prec, int64_t P, size_t* bytes) {
+    NetLayout L;
+    const int rc = build_layout(cfg, prec, &L);
+    if (rc) return rc;
+    if (!bytes || P < 0) { set_error("udf_vjp_workspace_bytes: bad argument"); return EMAP_E_INVALID; }
+    *bytes = plan_vjp(L, P).total;
+    return EMAP_OK;
+}
+
+int emap_udf_vjp(const EmapNetConfig* cfg, const void* packed, int prec, const float* x, int64_t P, const float* d_udf,
+                 const float* d_grad3, const EmapParamGrads* out, void* workspace, size_t workspace_bytes, int32_t* err_flags,
+                 void* stream) {
+    NetLayout L;
+    int rc = build_layout(cfg, prec, &L);
+    if (rc) return rc;
+    if (P < 0 || !packed || !workspace || (P > 0 && (!x || !d_udf || !d_grad3))) { set_error("udf_vjp: null pointer"); return EMAP_E_INVALID; }
+    rc = check_param_grads(L, out, "udf_vjp");
+    if (rc) return rc;
+    const VjpPlan pl = plan_vjp(L, P);
+    if (workspace_bytes < pl.total) { set_error("udf_vjp: workspace %zu < %zu bytes", workspace_bytes, pl.total); return EMAP_E_WORKSPACE; }
+    char* ws = static_cast<char*>(workspace);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    rc = launch_absmax(d_udf, d_grad3, P, reinterpret_cast<uint32_t*>(ws + pl.off_absmax), st);
+    if (rc) return rc;
+    PointSource src;
+    memset(&src, 0, sizeof(src));
+    src.x = x;
+    return run_vjp(L, packed, prec, src, P, d_udf, d_grad3, out, pl, ws, err_flags, st);
+}
+
+static size_t render_bwd_extra(const EmapRenderParams& p, size_t* off_du, size_t* off_dg, size_t* off_part) {
+    const size_t N = (size_t)std::max(p.n_rays, 0);
+    const int m = p.up_sample_steps > 0 ? p.n_importance / p.up_sample_steps : 0;
+    const size_t S = (size_t)p.n_samples + (size_t)m * std::max(p.up_sample_steps, 0);
+    size_t off = 0;
+    *off_du = off; off += align256(N * S * 4);
+    *off_dg = off; off += align256(N * S * 12);
+    *off_part = off; off += align256(N * 16);
+    return off;
+}
+
+int emap_render_bwd_workspace_bytes(const EmapNetConfig* cfg, int prec, const EmapRenderParams* p, size_t* bytes) {
+    NetLayout L;
+    const int rc = build_layout(cfg, prec, &L);
+    if (rc) return rc;
+    if (!p || !bytes) { set_error("render_bwd_workspace_bytes: null pointer"); return EMAP_E_INVALID; }
+    size_t a, b, c;
+    const size_t extra = render_bwd_extra(*p, &a, &b, &c);
+    const int m = p->up_sample_steps > 0 ? p->n_importance / p->up_sample_steps : 0;
+    const int64_t S = (int64_t)p->n_samples + (int64_t)m * std::max(p->up_sample_steps, 0);
+    *bytes = extra + plan_vjp(L, (int64_t)std::max(p->n_rays, 0) * S).total;
+    return EMAP_OK;
+}
+
+int emap_render_bwd(const EmapNetConfig* cfg, const void* packed, int prec, const EmapRenderParams* p, const float* rays_o,
+                    const float* rays_d, const float* depth_scale, const float* z_vals, const float* udf, const float* grad3,
+                    const float* sample_dist_dev, const EmapCompositeGrads* g, const EmapParamGrads* out, void* workspace,
+                    size_t workspace_bytes, int32_t* err_flags, void* stream) {
+    NetLayout L;
+    int rc = build_layout(cfg, prec, &L);
+    if (rc) return rc;
+    if (!p || !g || !packed || !rays_o || !rays_d || !z_vals || !udf || !grad3 || !sample_dist_dev || !workspace) {
+        set_error("render_bwd: null pointer");
+        return EMAP_E_INVALID;
+    }
+    rc = check_param_grads(L, out, "render_bwd");
+    if (rc) return rc;
+    const int N = p->n_rays;
+    if (N <= 0) return EMAP_OK;
+    const int m = p->up_sample_steps > 0 && p->n_importance > 0 ? p->n_importance / p->up_sample_steps : 0;
+    const int S = p->n_samples + m * (m > 0 ? p->up_sample_steps : 0);
+    size_t o_du, o_dg, o_part;
+    const size_t extra = render_bwd_extra(*p, &o_du, &o_dg, &o_part);
+    const VjpPlan pl = plan_vjp(L, (int64_t)N * S);
+    if (workspace_bytes < extra + pl.total) { set_error("render_bwd: workspace %zu < %zu bytes", workspace_bytes, extra + pl.total); return EMAP_E_WORKSPACE; }
+    char* ws = static_cast<char*>(workspace);
+    char* vws = ws + extra;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float* d_udf = reinterpret_cast<float*>(ws + o_du);
+    float* d_grad = reinterpret_cast<float*>(ws + o_dg);
+    // render_core's tail in reverse; it also leaves max|d_udf|, max|d_grad| for the sweep's range scale
+    rc = launch_composite_bwd(rays_o, rays_d, z_vals, udf, grad3, depth_scale, N, S, sample_dist_dev, p, g, d_udf, d_grad,
+                              reinterpret_cast<float*>(ws + o_part), reinterpret_cast<uint32_t*>(vws + pl.off_absmax), st);
+    if (rc) return rc;
+    PointSource fin;
+    memset(&fin, 0, sizeof(fin));
+    fin.rays_o = rays_o; fin.rays_d = rays_d; fin.z = z_vals; fin.n_per_ray = S; fin.mid = 1; fin.sample_dist = sample_dist_dev;
+    return run_vjp(L, packed, prec, fin, (int64_t)N * S, d_udf, d_grad, out, pl, vws, err_flags, st);
 }
 
 int emap_null_direction(const float* grads, int64_t n, int k, float* dir, void* stream) {

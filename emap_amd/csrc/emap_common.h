@@ -23,6 +23,15 @@ constexpr float F16X3_WS = 8192.0f;
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 
+// true the first time it is called for the current device with this mask (hipFuncSetAttribute is per function AND device)
+inline bool attr_needed(uint64_t& mask) {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d > 63) return true;
+    if (mask & (1ull << d)) return false;
+    mask |= 1ull << d;
+    return true;
+}
+
 // ---- packed-weight layout -------------------------------------------------------------------
 // The MLP kernels keep activations in registers in MFMA-fragment order and never transpose them:
 // the K dimension of layer l+1 is *permuted* so that the 8 k-values lane group g feeds to K-step s
@@ -66,8 +75,7 @@ struct NetLayout {
 // returns 0 or EMAP_E_INVALID (error text set)
 int build_layout(const EmapNetConfig* cfg, int prec, NetLayout* L);
 inline size_t layout_bytes(const NetLayout& L) {
-    return L.has_rev ? (size_t)L.t_frag_off_bytes + (size_t)L.t_total_frags * FRAG_BYTES
-                     : (size_t)L.frag_off_bytes + (size_t)L.total_frags * FRAG_BYTES;
+    return (size_t)L.t_frag_off_bytes + (size_t)L.t_total_frags * FRAG_BYTES;
 }
 
 // launchers implemented in the .hip files
@@ -84,15 +92,41 @@ struct PointSource {
     const float* sample_dist;  // device scalar (mid=1)
 };
 
-// scratch: device buffer of at least rev_scratch_bytes(L) for the reverse-mode grad kernel, or nullptr (a stream-ordered
-// temporary is allocated for the launch)
+// scratch: device buffer of at least rev_scratch_bytes(L) for the reverse-mode grad kernel (required when that kernel is
+// selected; mlp_uses_rev() tells)
 int launch_mlp(const NetLayout& L, const void* packed, int prec, const PointSource& src, int64_t P,
                float* udf, float* grad3, hipStream_t st, int32_t* err_flags = nullptr, void* scratch = nullptr);
 int launch_null_direction(const float* g, int64_t n, int k, float* dir, hipStream_t st);
 
+// ---- training backward (udf_mlp_vjp.inc, wgrad.hip) ---------------------------------------------------
+// The sweep kernel leaves the operands of the weight-gradient GEMM per tile of VJP_PT points in MFMA-fragment order
+// (K = columns: 64 per tile = 2 K-steps).  A "level" is a set of feature rows: rt row tiles x 2 K-steps x 1 KiB.
+//   A level 0 = PE slots (4 row tiles), A level l+1 = output of hidden layer l; Z level l = adjoint of layer l's pre-activation
+constexpr int VJP_PT = 32;
+constexpr int VJP_CHUNK_TILES = 2048;   // tiles per sweep launch (bounds the stash: 2048 x ~0.5 MiB)
+constexpr int WGRAD_MAX_JOBS = 2 * EMAP_MAX_LIN;
+struct VjpLayout {
+    int32_t a_rt[EMAP_MAX_LIN + 1], a_off[EMAP_MAX_LIN + 1];   // row tiles / KiB offset inside a tile's A block
+    int32_t z_rt[EMAP_MAX_LIN], z_off[EMAP_MAX_LIN];           // same for the Z block
+    int32_t s_off[EMAP_MAX_LIN];                               // KiB offset of layer l's sigma' inside a workgroup's slab
+    int32_t a_tile_kb, z_tile_kb, s_slab_kb;
+};
+void build_vjp_layout(const NetLayout& L, VjpLayout* V);
+// one weight-gradient GEMM job (wgrad.hip)
+struct WgradJob {
+    int32_t layer, part;
+    int32_t z_off, z_rt;        // KiB offset / row tiles of the Z level
+    int32_t a_off, a_ct;        // KiB offset / column tiles (= row tiles of the A level that are used)
+    int32_t first_wg, n_slices; // workgroups [first_wg, first_wg + n_slices)
+    int32_t part_off;           // offset of the job's partial block in floats: [slice][16 row tiles][a_ct][256]
+    int32_t bias_off;           // offset of the job's bias partials in floats: [slice][256] (part 0 jobs and layer 0 only, else -1)
+};
+
+
+bool mlp_uses_rev(const NetLayout& L, int prec, int64_t P);
 constexpr int REV_MAX_WG = 768;      // persistent workgroups of the reverse-mode kernel (3 per CU)
 inline size_t rev_scratch_bytes(const NetLayout& L) {   // sigmoid stash: [workgroup][layer][pair][4][64 lanes x 16 B]
-    return L.has_rev ? (size_t)REV_MAX_WG * (size_t)(L.n_lin - 1) * (size_t)(L.H / 32) * 4096 : 0;
+    return L.has_rev ? (size_t)(REV_MAX_WG * 2 / 3) * (size_t)(L.n_lin - 1) * (size_t)(L.H / 32) * 4096 : 0;   // 2 resident workgroups per CU
 }
 
 }  // namespace emap

@@ -423,6 +423,237 @@ __global__ __launch_bounds__(256) void composite_reduce_kernel(const float* part
 }
 
 // ---------------------------------------------------------------------------------------------
+// composite_bwd: reverse of render_core's tail (udf_renderer_blending.py:463-625 under autograd) - SURVEY par. 8 f1
+// ---------------------------------------------------------------------------------------------
+// Given dL/d{edge, depth} per ray and dL/d{gradient_error, gradient_error_near_surface}, produces dL/dudf (N,S),
+// dL/d(grad_x udf) (N,S,3) and per-ray partial sums of dL/d{inv_s, beta, gamma}.  The derivation (and its check against
+// torch.autograd through the oracle) is oracle/vjp_mirror.py:composite_bwd / tests/test_vjp_math.py.  One wave per ray;
+// the forward quantities are recomputed with the forward kernel's own expressions so that every clip / mask decision is
+// the one the forward took; the two cumprod adjoints are exclusive suffix sums (fp64 wave scans).
+__device__ __forceinline__ void wave_suffix_sum(const float* in, float* out, int n, int lane) {   // out[e] = sum_{k>e} in[k]
+    const int C = (n + 63) >> 6;
+    const int b = lane * C;       // chunk of REVERSED indices
+    double loc = 0.0;
+    for (int i = 0; i < C; ++i) { const int e = b + i; if (e < n) loc += (double)in[n - 1 - e]; }
+    double inc = loc;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double o = __shfl_up(inc, off);
+        if (lane >= off) inc += o;
+    }
+    double run = __shfl_up(inc, 1);
+    if (lane == 0) run = 0.0;
+    for (int i = 0; i < C; ++i) {
+        const int e = b + i;
+        if (e < n) { out[n - 1 - e] = (float)run; run += (double)in[n - 1 - e]; }
+    }
+}
+
+// backward of sdf2alpha(sdf, -tabs, dists, inv_s) for an upstream gradient dval on its clipped output
+__device__ __forceinline__ void sdf2alpha_bwd(float sdf, float tabs, float dists, float inv_s, bool anneal, float car, float dval,
+                                              float& d_sdf, float& d_tabs, float& d_inv_s) {
+    float ic = -tabs, dic = -1.0f;
+    if (anneal) {
+        ic = -((0.5f * tabs + 0.5f) * (1.0f - car) + tabs * car);
+        dic = -(0.5f * (1.0f - car) + ((tabs > 0.f) ? car : 0.f));
+    }
+    const float hh = ic * dists * 0.5f;
+    const float en = sdf + hh, ep = sdf - hh;
+    const float pc = sigmoidf_(ep * inv_s), nc = sigmoidf_(en * inv_s);
+    const float den = pc + 1e-5f;
+    const float val = (pc - nc + 1e-5f) / den;
+    const float dv = (val >= 0.f && val <= 1.f) ? dval : 0.f;
+    const float dpc = dv * nc / (den * den), dnc = -dv / den;
+    const float gp = dpc * pc * (1.0f - pc), gn = dnc * nc * (1.0f - nc);
+    d_inv_s = gp * ep + gn * en;
+    d_sdf = (gp + gn) * inv_s;
+    d_tabs = (gn - gp) * inv_s * dists * 0.5f * dic;
+}
+
+struct CompositeBwdArgs {
+    const float *rays_o, *rays_d, *z, *udf, *grad, *depth_scale, *sample_dist;
+    int N, S;
+    float inv_s, beta, gamma, car;
+    int anneal;
+    float flip_sat, near_surface, background;
+    int has_bg;
+    const float *var_p, *beta_p, *gamma_p;
+    float beta_min;
+    const float *d_edge, *d_depth;      // (N) or null
+    const float *d_ge, *d_ge_ns;        // device scalars or null
+    const float* scalars;               // the forward's scalars: [4] = sum(relax), [6] = sum(near)
+    float *d_udf, *d_grad;              // (N,S), (N,S,3)
+    float* partials;                    // (N,4): per-ray d_inv_s, d_beta, d_gamma
+    uint32_t* absmax;                   // [2]: max|d_udf|, max|d_grad| (atomicMax), may be null
+};
+
+__global__ __launch_bounds__(64) void composite_bwd_kernel(const CompositeBwdArgs a) {
+    __shared__ float s_z[MAXS], s_tc[MAXS], s_eq[MAXS], s_ain[MAXS], s_a[MAXS], s_vp[MAXS], s_ap[MAXS], s_am[MAXS], s_om[MAXS],
+        s_T[MAXS], s_x[MAXS], s_suf[MAXS], s_dal[MAXS];
+    const int ray = blockIdx.x, lane = threadIdx.x, S = a.S;
+    const float ox = a.rays_o[3 * ray], oy = a.rays_o[3 * ray + 1], oz = a.rays_o[3 * ray + 2];
+    const float dx = a.rays_d[3 * ray], dy = a.rays_d[3 * ray + 1], dz = a.rays_d[3 * ray + 2];
+    const float sd = *a.sample_dist;
+    float inv_s_ = a.inv_s, beta_ = a.beta, gamma_ = a.gamma;
+    if (a.var_p) {
+        inv_s_ = clipf(expf(FMUL(a.var_p[0], 10.0f)), 1e-6f, 1e6f);
+        beta_ = clipf(clipf(expf(FMUL(a.beta_p[0], 10.0f)), 0.0f, FDIV(1.0f, a.beta_min)), 1e-6f, 1e6f);
+        gamma_ = clipf(expf(FMUL(a.gamma_p[0], 10.0f)), 1e-6f, 1e6f);
+    }
+    const size_t rb = (size_t)ray * S;
+    const float g_edge = a.d_edge ? a.d_edge[ray] * (a.has_bg ? (1.0f - a.background) : 1.0f) : 0.f;
+    const float g_depth = a.d_depth ? a.d_depth[ray] * (a.depth_scale ? a.depth_scale[ray] : 1.0f) : 0.f;
+    const float c_ge = a.d_ge ? a.d_ge[0] / (a.scalars[4] + 1e-5f) : 0.f;
+    const float c_ns = a.d_ge_ns ? a.d_ge_ns[0] / (a.scalars[6] + 1e-5f) : 0.f;
+    for (int e = lane; e < S; e += 64) s_z[e] = a.z[rb + e];
+    __syncthreads();
+    for (int e = lane; e < S; e += 64) {
+        const float gx = a.grad[3 * (rb + e)], gy = a.grad[3 * (rb + e) + 1], gz = a.grad[3 * (rb + e) + 2];
+        s_tc[e] = FADD(FADD(FMUL(dx, gx), FMUL(dy, gy)), FMUL(dz, gz));
+        const float dists = (e < S - 1) ? FSUB(s_z[e + 1], s_z[e]) : sd;
+        const float raw_occ = udf2logistic1(a.udf[rb + e], beta_);
+        s_eq[e] = expf(FMUL(FMUL(-relu_(raw_occ), gamma_), dists));            // 1 - alpha_occ up to rounding
+    }
+    __syncthreads();
+    for (int e = lane; e < S; e += 64) {
+        const float vis_mask = (e < S - 1) ? ((s_tc[e + 1] < 0.01f) ? 1.0f : 0.0f) : 1.0f;
+        const float occ = FSUB(1.0f, s_eq[e]);
+        const float ain = FADD(FSUB(1.0f, occ), FMUL(a.flip_sat, vis_mask));
+        s_ain[e] = ain;
+        s_a[e] = FADD(clipf(ain, 0.0f, 1.0f), 1e-7f);
+    }
+    __syncthreads();
+    wave_scan<true>(s_a, s_vp, S, lane);       // raw (unclipped) visibility product
+    __syncthreads();
+    for (int e = lane; e < S; e += 64) {
+        const float vp = clipf(s_vp[e], 0.0f, 1.0f);
+        const float dists = (e < S - 1) ? FSUB(s_z[e + 1], s_z[e]) : sd;
+        const float u = a.udf[rb + e];
+        const float tc = -fabsf(s_tc[e]);
+        const float ap = sdf2alpha(u, tc, dists, inv_s_, a.anneal != 0, a.car);
+        const float am = sdf2alpha(-u, tc, dists, inv_s_, a.anneal != 0, a.car);
+        const float alpha = FADD(FMUL(ap, vp), FMUL(am, FSUB(1.0f, vp)));
+        s_ap[e] = ap; s_am[e] = am;
+        s_om[e] = FADD(FSUB(1.0f, alpha), 1e-7f);
+    }
+    __syncthreads();
+    wave_scan<true>(s_om, s_T, S, lane);       // transmittance
+    __syncthreads();
+    for (int e = lane; e < S; e += 64) {
+        const float vp = clipf(s_vp[e], 0.0f, 1.0f);
+        const float alpha = FADD(FMUL(s_ap[e], vp), FMUL(s_am[e], FSUB(1.0f, vp)));
+        const float dists = (e < S - 1) ? FSUB(s_z[e + 1], s_z[e]) : sd;
+        const float mid = FADD(s_z[e], FMUL(dists, 0.5f));
+        const float dw = g_edge + g_depth * mid;
+        s_dal[e] = dw;                          // dL/dw_e for now
+        s_x[e] = dw * alpha * s_T[e];           // dw_e * w_e
+    }
+    __syncthreads();
+    wave_suffix_sum(s_x, s_suf, S, lane);
+    __syncthreads();
+    for (int e = lane; e < S; e += 64) {
+        const float dalpha = s_dal[e] * s_T[e] - s_suf[e] / s_om[e];
+        s_dal[e] = dalpha;
+        const float vr = s_vp[e];
+        const float dvp = (vr >= 0.f && vr <= 1.f) ? dalpha * (s_ap[e] - s_am[e]) : 0.f;
+        s_x[e] = dvp * vr;
+    }
+    __syncthreads();
+    wave_suffix_sum(s_x, s_suf, S, lane);
+    __syncthreads();
+    double p_is = 0.0, p_beta = 0.0, p_gamma = 0.0;
+    float mx_u = 0.f, mx_g = 0.f;
+    for (int e = lane; e < S; e += 64) {
+        const float dists = (e < S - 1) ? FSUB(s_z[e + 1], s_z[e]) : sd;
+        const float mid = FADD(s_z[e], FMUL(dists, 0.5f));
+        const float u = a.udf[rb + e];
+        const float gx = a.grad[3 * (rb + e)], gy = a.grad[3 * (rb + e) + 1], gz = a.grad[3 * (rb + e) + 2];
+        // occlusion branch: a_i = clip(1 - occ + fs*vm) + 1e-7
+        const float da = s_suf[e] / s_a[e];
+        const float docc = (s_ain[e] >= 0.f && s_ain[e] <= 1.f) ? -da : 0.f;
+        const float dq = docc * s_eq[e];
+        const float E = expf(-beta_ * u);
+        const float opE = 1.0f + E;
+        const float raw = beta_ * E / (opE * opE);
+        const float draw = (raw > 0.f) ? dq * gamma_ * dists : 0.f;
+        p_gamma += (double)(dq * relu_(raw) * dists);
+        const float fE = (1.0f - E) / (opE * opE * opE);
+        float du = draw * (-beta_ * beta_ * E * fE);
+        p_beta += (double)(draw * (E / (opE * opE) - beta_ * u * E * fE));
+        // alpha branch
+        const float vp = clipf(s_vp[e], 0.0f, 1.0f);
+        const float dalpha = s_dal[e];
+        const float tabs = fabsf(s_tc[e]);
+        float s1, t1, i1, s2, t2, i2;
+        sdf2alpha_bwd(u, tabs, dists, inv_s_, a.anneal != 0, a.car, dalpha * vp, s1, t1, i1);
+        sdf2alpha_bwd(-u, tabs, dists, inv_s_, a.anneal != 0, a.car, dalpha * (1.0f - vp), s2, t2, i2);
+        du += s1 - s2;
+        p_is += (double)(i1 + i2);
+        const float tcv = s_tc[e];
+        const float dtc = (t1 + t2) * ((tcv > 0.f) ? 1.f : ((tcv < 0.f) ? -1.f : 0.f));
+        // eikonal terms (:612-625), masks detached
+        const float px = FADD(ox, FMUL(dx, mid)), py = FADD(oy, FMUL(dy, mid)), pz = FADD(oz, FMUL(dz, mid));
+        const float pn = sqrtf(FADD(FADD(FMUL(px, px), FMUL(py, py)), FMUL(pz, pz)));
+        const float gm = sqrtf(FADD(FADD(FMUL(gx, gx), FMUL(gy, gy)), FMUL(gz, gz)));
+        const float relax = (pn < 2.4f) ? 1.0f : 0.0f, ns = (u < a.near_surface) ? 1.0f : 0.0f;
+        const float coef = (gm > 0.f) ? (c_ge * relax + c_ns * ns) * 2.0f * (gm - 1.0f) / gm : 0.f;
+        const float ogx = dtc * dx + coef * gx, ogy = dtc * dy + coef * gy, ogz = dtc * dz + coef * gz;
+        a.d_udf[rb + e] = du;
+        a.d_grad[3 * (rb + e)] = ogx; a.d_grad[3 * (rb + e) + 1] = ogy; a.d_grad[3 * (rb + e) + 2] = ogz;
+        const float au = fabsf(du), ag = fmaxf(fmaxf(fabsf(ogx), fabsf(ogy)), fabsf(ogz));
+        mx_u = (au < 3.0e38f) ? fmaxf(mx_u, au) : mx_u;
+        mx_g = (ag < 3.0e38f) ? fmaxf(mx_g, ag) : mx_g;
+    }
+    p_is = wave_sum_d(p_is); p_beta = wave_sum_d(p_beta); p_gamma = wave_sum_d(p_gamma);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { mx_u = fmaxf(mx_u, __shfl_xor(mx_u, off)); mx_g = fmaxf(mx_g, __shfl_xor(mx_g, off)); }
+    if (lane == 0) {
+        float* p = a.partials + (size_t)ray * 4;
+        p[0] = (float)p_is; p[1] = (float)p_beta; p[2] = (float)p_gamma; p[3] = 0.f;
+        if (a.absmax) {
+            atomicMax(a.absmax, __builtin_bit_cast(uint32_t, mx_u));
+            atomicMax(a.absmax + 1, __builtin_bit_cast(uint32_t, mx_g));
+        }
+    }
+}
+
+// deterministic cross-ray sum of the scalar-parameter gradients and the chain through x = exp(10 p).clip(...)
+// (udf_model.py:226-227,259-263, udf_renderer_blending.py:466-472): d_param[0..2] = dL/d{variance, beta, gamma}
+__global__ __launch_bounds__(256) void composite_bwd_reduce_kernel(const float* partials, int N, const CompositeBwdArgs a,
+                                                                   float* d_variance, float* d_beta, float* d_gamma, float grad_scale,
+                                                                   int accumulate) {
+    __shared__ double red[4][3];
+    double v[3] = {0, 0, 0};
+    for (int i = threadIdx.x; i < N; i += 256)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) v[k] += (double)partials[(size_t)i * 4 + k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) v[k] = wave_sum_d(v[k]);
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) red[threadIdx.x >> 6][k] = v[k];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t[3];
+        for (int k = 0; k < 3; ++k) t[k] = red[0][k] + red[1][k] + red[2][k] + red[3][k];
+        float r_var = 0.f, r_beta = 0.f, r_gamma = 0.f;
+        if (a.var_p) {
+            const float xs = expf(FMUL(a.var_p[0], 10.0f));
+            if (xs >= 1e-6f && xs <= 1e6f) r_var = (float)t[0] * 10.0f * xs;
+            const float xb = expf(FMUL(a.beta_p[0], 10.0f)), hi = FDIV(1.0f, a.beta_min);
+            if (xb >= 0.f && xb <= hi && xb >= 1e-6f && xb <= 1e6f) r_beta = (float)t[1] * 10.0f * xb;
+            const float xg = expf(FMUL(a.gamma_p[0], 10.0f));
+            if (xg >= 1e-6f && xg <= 1e6f) r_gamma = (float)t[2] * 10.0f * xg;
+        } else {   // by-value scalars: report the gradients w.r.t. inv_s, beta, gamma themselves
+            r_var = (float)t[0]; r_beta = (float)t[1]; r_gamma = (float)t[2];
+        }
+        if (d_variance) d_variance[0] = (accumulate ? d_variance[0] : 0.f) + r_var * grad_scale;
+        if (d_beta) d_beta[0] = (accumulate ? d_beta[0] : 0.f) + r_beta * grad_scale;
+        if (d_gamma) d_gamma[0] = (accumulate ? d_gamma[0] : 0.f) + r_gamma * grad_scale;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Embedder.embed (embedder.py:34-35): x (P,3) -> (P, 3+6L), reference column order
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void embed_kernel(const float* x, long long P, int L, float* pe) {
@@ -500,6 +731,29 @@ int launch_composite(const float* rays_o, const float* rays_d, const float* z, c
     hipLaunchKernelGGL(composite_kernel, dim3(N), dim3(64), 0, st, a);
     if (out->scalars) hipLaunchKernelGGL(composite_reduce_kernel, dim3(1), dim3(256), 0, st, partials, N, out->scalars, err, a);
     return check_launch("composite");
+}
+
+int launch_composite_bwd(const float* rays_o, const float* rays_d, const float* z, const float* udf, const float* grad3,
+                         const float* depth_scale, int N, int S, const float* sample_dist, const EmapRenderParams* p,
+                         const EmapCompositeGrads* gr, float* d_udf, float* d_grad3, float* partials, uint32_t* absmax,
+                         hipStream_t st) {
+    if (S < 1 || S > MAXS) { set_error("composite_bwd: S=%d out of range (max %d)", S, MAXS); return EMAP_E_INVALID; }
+    if (N <= 0) return EMAP_OK;
+    CompositeBwdArgs a;
+    a.rays_o = rays_o; a.rays_d = rays_d; a.z = z; a.udf = udf; a.grad = grad3; a.depth_scale = depth_scale;
+    a.sample_dist = sample_dist; a.N = N; a.S = S; a.inv_s = p->inv_s; a.beta = p->beta; a.gamma = p->gamma; a.car = p->cos_anneal_ratio;
+    a.anneal = p->has_cos_anneal; a.flip_sat = p->flip_saturation; a.near_surface = p->near_surface;
+    a.background = p->background; a.has_bg = p->has_background;
+    a.var_p = p->variance_dev; a.beta_p = p->beta_dev; a.gamma_p = p->gamma_dev; a.beta_min = p->beta_min;
+    if (a.var_p && (!a.beta_p || !a.gamma_p)) { set_error("composite_bwd: variance_dev given without beta_dev/gamma_dev"); return EMAP_E_INVALID; }
+    a.d_edge = gr->d_edge; a.d_depth = gr->d_depth; a.d_ge = gr->d_gradient_error; a.d_ge_ns = gr->d_gradient_error_near_surface;
+    a.scalars = gr->scalars; a.d_udf = d_udf; a.d_grad = d_grad3; a.partials = partials; a.absmax = absmax;
+    if ((a.d_ge || a.d_ge_ns) && !a.scalars) { set_error("composite_bwd: the eikonal gradients need the forward's scalars"); return EMAP_E_INVALID; }
+    if (absmax && hipMemsetAsync(absmax, 0, 8, st) != hipSuccess) { set_error("hipMemsetAsync failed"); return EMAP_E_LAUNCH; }
+    hipLaunchKernelGGL(composite_bwd_kernel, dim3(N), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(composite_bwd_reduce_kernel, dim3(1), dim3(256), 0, st, partials, N, a, gr->d_variance, gr->d_beta,
+                       gr->d_gamma, gr->grad_scale, gr->accumulate);
+    return check_launch("composite_bwd");
 }
 
 int launch_embed(const float* x, int64_t P, int L, float* pe, hipStream_t st) {

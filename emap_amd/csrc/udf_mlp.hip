@@ -196,7 +196,8 @@ __global__ __launch_bounds__(256) void pack_wlast_kernel(const PackArgs a) {
     if (f >= H) return;
     const float* rs = reinterpret_cast<const float*>(a.packed + a.L.rowscale_off_bytes);
     float* wl = reinterpret_cast<float*>(a.packed + a.L.wlast_off_bytes);
-    wl[f] = (f < a.L.layer[l].in_prev) ? rs[l * H] * a.v[l][f] : 0.f;
+    const float mult = (l == a.L.skip_l) ? 0.70710678118654752440f : 1.0f;   // skip layer == last layer (d4 networks)
+    wl[f] = (f < a.L.layer[l].in_prev) ? rs[l * H] * a.v[l][f] * mult : 0.f;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -246,8 +247,23 @@ int build_layout(const EmapNetConfig* cfg, int prec, NetLayout* L) {
         if (l >= 1 && l < cfg->n_lin - 1) { L->t_off[l] = tf; tf += ((L->layer[l].in_prev + 31) / 32) * (H / 32) * 2 * L->nparts; }
         if (l == 0 || l == cfg->skip_l) { L->tpe_off[l] = tf; tf += 2 * (H / 32) * 2 * L->nparts; }
     }
-    L->t_total_frags = L->has_rev ? tf : 0;
+    L->t_total_frags = tf;   // always packed: the training backward (udf_mlp_vjp.inc) needs it for every topology
     return EMAP_OK;
+}
+
+void build_vjp_layout(const NetLayout& L, VjpLayout* V) {
+    memset(V, 0, sizeof(*V));
+    int a = 0, z = 0, s = 0;
+    V->a_rt[0] = 2 * PE_KS; V->a_off[0] = a; a += V->a_rt[0] * 2;
+    for (int l = 0; l < L.n_lin; ++l) {
+        const bool last = (l == L.n_lin - 1);
+        if (!last) {
+            V->a_rt[l + 1] = 2 * L.layer[l].n_pairs; V->a_off[l + 1] = a; a += V->a_rt[l + 1] * 2;
+            V->s_off[l] = s; s += 2 * L.layer[l].n_pairs;
+        }
+        V->z_rt[l] = last ? 1 : 2 * L.layer[l].n_pairs; V->z_off[l] = z; z += V->z_rt[l] * 2;
+    }
+    V->a_tile_kb = a; V->z_tile_kb = z; V->s_slab_kb = s;
 }
 
 int launch_pack(const NetLayout& L, const float* const* g, const float* const* v, const float* const* b,
@@ -263,7 +279,7 @@ int launch_pack(const NetLayout& L, const float* const* g, const float* const* v
     hipLaunchKernelGGL(rowscale_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, a);
     const long long threads = (long long)L.total_frags * 64;
     hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, a);
-    if (L.has_rev) {
+    {
         const long long tthreads = (long long)L.t_total_frags * 64;
         hipLaunchKernelGGL(pack_t_kernel, dim3((unsigned)((tthreads + 255) / 256)), dim3(256), 0, st, a);
         hipLaunchKernelGGL(pack_wlast_kernel, dim3((L.H + 255) / 256), dim3(256), 0, st, a);
@@ -299,6 +315,8 @@ static int mlp_variant(const NetLayout& L, int prec, int64_t P, bool grad) {
     (void)prec; (void)P;
     return 2;   // fs2 (two or three workgroups per CU) measured fastest or equal at every size and mode on MI355X
 }
+
+bool mlp_uses_rev(const NetLayout& L, int prec, int64_t P) { return mlp_variant(L, prec, P, true) == 3; }
 
 int launch_mlp(const NetLayout& L, const void* packed, int prec, const PointSource& src, int64_t P, float* udf,
                float* grad3, hipStream_t st, int32_t* err_flags, void* scratch) {

@@ -11,4 +11,10 @@ int launch_mlp_f16x3(const NetLayout& L, const void* packed, const PointSource& 
     if (variant == 1) return launch_mlp_fs_mode<EMAP_PREC_F16X3>(L, packed, src, P, udf, grad3, st, err);
     return launch_mlp_mode<EMAP_PREC_F16X3>(L, packed, src, P, udf, grad3, st, err);
 }
+int launch_vjp_sweep_f16x3(const NetLayout& L, const void* packed, const PointSource& src, int64_t P, int tile0, int n_tiles,
+                            const float* d_udf, const float* d_grad, const VjpLayout& V, char* stash_a, char* stash_z, char* stash_s,
+                            int grid, const uint32_t* absmax, hipStream_t st, int32_t* err) {
+    return launch_vjp_sweep_mode<EMAP_PREC_F16X3>(L, packed, src, P, tile0, n_tiles, d_udf, d_grad, V, stash_a, stash_z, stash_s, grid,
+                                                 absmax, st, err);
+}
 }  // namespace emap

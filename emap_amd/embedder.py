@@ -26,7 +26,7 @@ class Embedder:
 
     def embed(self, inputs: torch.Tensor) -> torch.Tensor:
         if inputs.requires_grad and torch.is_grad_enabled():
-            return embed_torch(inputs, self.num_freqs)  # differentiable path (interim backward, SURVEY par. 8 f1)
+            return embed_torch(inputs, self.num_freqs)  # a caller that wants d(PE)/d(inputs) from autograd (not on the render path)
         if self.input_dims != 3 or not self.include_input:
             raise NotImplementedError("the HIP embedder handles input_dims=3 with include_input=True")
         _lib.require_cuda(inputs, "inputs")
@@ -37,7 +37,7 @@ class Embedder:
 
 
 def embed_torch(x: torch.Tensor, multires: int) -> torch.Tensor:
-    """Differentiable torch formulation of the same encoding (used only by the interim backward)."""
+    """Differentiable torch formulation of the same encoding (RenderingNetwork view directions; inputs that require grad)."""
     outs = [x]
     for k in range(multires):
         f = float(2 ** k)

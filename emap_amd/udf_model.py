@@ -9,10 +9,9 @@ What differs is *how* ``forward`` / ``udf`` / ``gradient`` are evaluated: one fu
 (positional encoding + all Linear/Softplus layers [+ forward-mode spatial gradient]) reading a packed
 copy of the weight-normed weights that is rebuilt only when a parameter changes.
 
-Autograd: parameter/input gradients (training) go through ``emap_amd._interim_backward`` - a
-PyTorch-ROCm recomputation on the GPU, the interim stated in SURVEY.md par. 8(f1) until the
-``udf_mlp_vjp`` kernels land.  Inference calls (``torch.no_grad()`` or nothing requiring grad) are
-pure HIP.
+Autograd: with grad mode on and trainable parameters, ``forward`` / ``udf`` / ``gradient`` run inside
+``emap_amd.backward.UdfFn`` - HIP forward, HIP parameter gradients (``emap_udf_vjp``: the double backward of
+udf_model.py:121-135 as kernels).  There is no PyTorch evaluation of the network anywhere in this package.
 """
 from __future__ import annotations
 
@@ -78,6 +77,9 @@ class UDFNetwork(nn.Module):
         self.activation = nn.Softplus(beta=100)
         self.relu = nn.ReLU()
         self._pack_cache = {}
+        self._vjp_ws = {}
+        self._scratch = {}
+        self._err = None
 
     # ---- packed weights -----------------------------------------------------------------------
     def _gvb(self):
@@ -110,7 +112,9 @@ class UDFNetwork(nn.Module):
         prec = _lib.PRECISIONS[precision or self.precision]
         gs, vs, bs = self._gvb()
         _lib.require_cuda(vs[0], "UDFNetwork parameters")
-        key = (prec, vs[0].device, tuple(int(t._version) for t in gs + vs + bs), tuple(t.data_ptr() for t in vs))
+        # version counters catch optimizer steps / in-place ops; the data pointers catch re-assigned .data; edits made through
+        # `.data` in place bump neither - call invalidate_packed() after those
+        key = (prec, vs[0].device, tuple(int(t._version) for t in gs + vs + bs), tuple(t.data_ptr() for t in gs + vs + bs))
         hit = self._pack_cache.get(prec)
         if hit is not None and hit[0] == key:
             return hit[1]
@@ -130,6 +134,15 @@ class UDFNetwork(nn.Module):
         self._pack_cache[prec] = (key, buf)
         return buf
 
+    def invalidate_packed(self):
+        """Force a re-pack on the next call (after editing parameters through ``.data`` in place)."""
+        self._pack_cache = {}
+
+    def err_word(self, dev):
+        if self._err is None or self._err.device != dev:
+            self._err = torch.zeros(1, dtype=torch.int32, device=dev)
+        return self._err
+
     # ---- HIP evaluation -----------------------------------------------------------------------
     def _needs_autograd(self, x):
         return torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
@@ -146,12 +159,22 @@ class UDFNetwork(nn.Module):
         L = _lib.lib()
         if P == 0:
             return udf, (torch.empty(0, 3, device=xs.device, dtype=torch.float32) if with_grad else None)
-        if with_grad:
-            grad = torch.empty(P, 3, device=xs.device, dtype=torch.float32)
-            _lib.check(L.emap_udf_fwd_grad(C.byref(cfg), _lib.ptr(buf), prec, _lib.ptr(xs), P, _lib.ptr(udf), _lib.ptr(grad),
-                                          _lib.stream_ptr()), "udf_fwd_grad")
-            return udf, grad
-        _lib.check(L.emap_udf_fwd(C.byref(cfg), _lib.ptr(buf), prec, _lib.ptr(xs), P, _lib.ptr(udf), _lib.stream_ptr()), "udf_fwd")
+        with _lib.on_device(xs):
+            if with_grad:
+                grad = torch.empty(P, 3, device=xs.device, dtype=torch.float32)
+                nb = C.c_size_t()
+                _lib.check(L.emap_udf_scratch_bytes(C.byref(cfg), prec, P, C.byref(nb)), "udf_scratch_bytes")
+                scr = None
+                if nb.value:
+                    scr = self._scratch.get(xs.device)
+                    if scr is None or scr.numel() < nb.value:
+                        scr = torch.empty(nb.value, dtype=torch.uint8, device=xs.device)
+                        self._scratch = {xs.device: scr}
+                _lib.check(L.emap_udf_fwd_grad(C.byref(cfg), _lib.ptr(buf), prec, _lib.ptr(xs), P, _lib.ptr(udf), _lib.ptr(grad),
+                                              _lib.ptr(scr), nb.value, _lib.stream_ptr(xs.device)), "udf_fwd_grad")
+                return udf, grad
+            _lib.check(L.emap_udf_fwd(C.byref(cfg), _lib.ptr(buf), prec, _lib.ptr(xs), P, _lib.ptr(udf),
+                                     _lib.stream_ptr(xs.device)), "udf_fwd")
         return udf, None
 
     # ---- reference interface ------------------------------------------------------------------
@@ -167,9 +190,10 @@ class UDFNetwork(nn.Module):
         _lib.require_cuda(inputs, "inputs")
         _lib.lib()
         if self._needs_autograd(inputs):
-            from ._interim_backward import udf_forward_torch
-            return udf_forward_torch(self, inputs)
-        udf, _ = self.hip_udf(inputs)
+            from .backward import UdfFn
+            udf, _ = UdfFn.apply(self, inputs, False, *self.parameters())
+        else:
+            udf, _ = self.hip_udf(inputs)
         pe = self.embed_fn_fine(inputs.detach() * self.scale)
         return udf, pe
 
@@ -184,10 +208,11 @@ class UDFNetwork(nn.Module):
         """-> (P,1,3) grad_x udf   (udf_model.py:121-135; differentiable when grads are enabled)."""
         _lib.require_cuda(x, "x")
         _lib.lib()
-        if self._needs_autograd(x) and any(p.requires_grad for p in self.parameters()):
-            from ._interim_backward import udf_gradient_torch
-            return udf_gradient_torch(self, x)
-        _, g = self.hip_udf(x, with_grad=True)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            from .backward import UdfFn
+            _, g = UdfFn.apply(self, x.detach(), True, *self.parameters())   # the reference re-leafs x too (:122)
+        else:
+            _, g = self.hip_udf(x, with_grad=True)
         return g.unsqueeze(1)
 
 

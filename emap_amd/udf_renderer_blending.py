@@ -1,7 +1,9 @@
 """Renderer with the reference interface (reference src/models/udf_renderer_blending.py:112-975),
 evaluated by libemap_hip: ``render()`` enqueues the coarse sampler, the MLP passes, the K
 occlusion-aware up-sampling steps, the final MLP value+gradient pass and the compositing kernel on the
-current stream in ONE C call with no host synchronisation.
+current stream in ONE C call with no host synchronisation.  With trainable parameters and grad mode on,
+the same forward runs inside ``emap_amd.backward.RenderFn`` and ``loss.backward()`` is ONE more C call
+(``emap_render_bwd``: composite_bwd + the MLP double-backward kernels); there is no PyTorch fallback.
 
 Supported configuration = what every EMAP conf selects (SURVEY.md par. 2 #5-#7):
 ``sdf2alpha_type="numerical"``, ``upsampling_type="classical"``, ``use_unbias_render=True``,
@@ -14,7 +16,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._interim_backward import RenderCoreInterim, DIFF_KEYS
+from .backward import ParamLayout, RenderFn, _workspace
 
 _PER_SAMPLE = ("weights", "alpha", "mid_z", "dists", "inside_sphere", "gradient_mag")
 
@@ -60,7 +62,10 @@ class UDFRendererBlending:
         self.device = device
         self.precision = precision  # None -> udf_network.precision
         self._ws = {}
+        self._bws = {}
         self._err = None
+        self._lay = None
+        self._const = {}
 
     # ---- helpers ------------------------------------------------------------------------------
     @property
@@ -103,23 +108,27 @@ class UDFRendererBlending:
                                f"{'MLP output (fp16 range exceeded? use precision=bf16x3) ' if f & _lib.F_MLP_NONFINITE else ''})")
 
     # ---- reference interface ------------------------------------------------------------------
-    def render(self, rays_o, rays_d, near, far, depth_scale, cos_anneal_ratio=None, perturb_overwrite=-1,
-               background_rgb=None, flip_saturation=0, color_maps=None, pose=None, fx=None, fy=None, img_index=None,
-               rays_uv=None, t_rand=None):
-        """reference udf_renderer_blending.py:679-800.  Extra keyword `t_rand` ((N,1) in [-0.5,0.5)) injects
-        the jitter draw (tests); otherwise it is drawn exactly like the reference: torch.rand([N,1]) on the
-        CPU generator (:719)."""
+    def _layout(self) -> ParamLayout:
+        if self._lay is None:
+            self._lay = ParamLayout(self.udf_network, self.deviation_network, self.beta_network)
+        return self._lay
+
+    def _prepare(self, rays_o, rays_d, near, far, depth_scale, cos_anneal_ratio, perturb_overwrite, background_rgb,
+                 flip_saturation, t_rand, reduced=False):
         _lib.require_cuda(rays_o, "rays_o")
         dev = rays_o.device
         N = len(rays_o)
-        S = self.samples_per_ray
         net = self.udf_network
         prec_name = self.precision or net.precision
-        prec = _lib.PRECISIONS[prec_name]
         ro, rd = _lib.f32c(rays_o.detach()), _lib.f32c(rays_d.detach())
         if not isinstance(near, torch.Tensor):
-            near_t = torch.full((N,), float(near), device=dev, dtype=torch.float32)
-            far_t = torch.full((N,), float(far), device=dev, dtype=torch.float32)
+            key = ("nf", N, float(near), float(far), dev)
+            nf = self._const.get(key)
+            if nf is None:
+                nf = (torch.full((N,), float(near), device=dev, dtype=torch.float32),
+                      torch.full((N,), float(far), device=dev, dtype=torch.float32))
+                self._const = {key: nf}
+            near_t, far_t = nf
         else:
             near_t = _lib.f32c(near.detach().to(dev)).reshape(-1).expand(N).contiguous()
             far_t = _lib.f32c(far.detach().to(dev)).reshape(-1).expand(N).contiguous()
@@ -128,41 +137,127 @@ class UDFRendererBlending:
         if t_rand is not None:
             tr = _lib.f32c(t_rand.to(dev)).reshape(-1)
         elif perturb > 0:
-            tr = (torch.rand([N, 1]) - 0.5).to(dev).reshape(-1)
+            tr = (torch.rand([N, 1]) - 0.5).to(dev).reshape(-1)   # the reference's CPU-generator draw (:719)
         ds = _lib.f32c(depth_scale.detach().to(dev)).reshape(-1) if depth_scale is not None else None
+        return {"N": N, "S": self.samples_per_ray, "dev": dev, "prec_name": prec_name, "ro": ro, "rd": rd, "near": near_t,
+                "far": far_t, "t_rand": tr, "ds": ds, "reduced": reduced,
+                "p": self._params(N, cos_anneal_ratio, flip_saturation, background_rgb)}
 
-        # one flat output allocation, sliced into views
-        sizes = {"z_vals": N * S, "udf": N * S, "gradients": N * S * 3, "gradients_flip": N * S * 3, "edge": N, "depth": N,
-                 "weight_sum": N, "normals": N * 3, "scalars": 16}
-        for k in _PER_SAMPLE:
-            sizes[k] = N * S
+    def _render_hip(self, call):
+        """One emap_render_fwd call.  Returns the dict of flat output views (full: every per-sample entry of the
+        reference's dict; reduced: only edge / depth / normals / weight_sum / scalars are written - 28 B per ray instead
+        of 48 B per sample, the mode of the full-image path, SURVEY par. 8 f4)."""
+        N, S, dev, reduced = call["N"], call["S"], call["dev"], call["reduced"]
+        net = self.udf_network
+        prec = _lib.PRECISIONS[call["prec_name"]]
+        per_ray = {"edge": N, "depth": N, "weight_sum": N, "normals": N * 3, "scalars": 16}
+        mlp_out = {"z_vals": N * S, "udf": N * S, "gradients": N * S * 3}
+        sizes = dict(per_ray)
+        if not reduced:
+            sizes.update(mlp_out)
+            sizes["gradients_flip"] = N * S * 3
+            for k in _PER_SAMPLE:
+                sizes[k] = N * S
         flat = torch.empty(sum(sizes.values()), device=dev, dtype=torch.float32)
         v, off = {}, 0
         for k, n in sizes.items():
             v[k] = flat[off:off + n]
             off += n
-
-        p = self._params(N, cos_anneal_ratio, flip_saturation, background_rgb)
+        if reduced:   # the MLP's own outputs are intermediates here: a cached scratch, not a fresh allocation
+            sc = _workspace(self._const.setdefault("_scr", {}), (N, S), 4 * sum(mlp_out.values()), dev).view(torch.float32)
+            off = 0
+            for k, n in mlp_out.items():
+                v[k] = sc[off:off + n]
+                off += n
+        p = call["p"]
         L = _lib.lib()
-        key = (N, dev)
-        ws = self._ws.get(key)
-        if ws is None:
-            nb = C.c_size_t()
-            _lib.check(L.emap_render_workspace_bytes(C.byref(p), C.byref(nb)), "render_workspace_bytes")
-            ws = torch.empty(nb.value, dtype=torch.uint8, device=dev)
-            self._ws = {key: ws}
-        if self._err is None or self._err.device != dev:
-            self._err = torch.zeros(1, dtype=torch.int32, device=dev)
-        co = _lib.CompositeOut()
-        for k in _PER_SAMPLE + ("gradients_flip", "edge", "depth", "weight_sum", "normals", "scalars"):
-            setattr(co, k, v[k].data_ptr())
         cfg = net.net_config()
-        packed = net.packed(prec_name)
-        _lib.check(L.emap_render_fwd(C.byref(cfg), _lib.ptr(packed), prec, C.byref(p), _lib.ptr(ro), _lib.ptr(rd),
-                                     _lib.ptr(near_t), _lib.ptr(far_t), _lib.ptr(tr), _lib.ptr(ds), _lib.ptr(v["z_vals"]),
-                                     _lib.ptr(v["udf"]), _lib.ptr(v["gradients"]), C.byref(co), _lib.ptr(ws), ws.numel(),
-                                     _lib.ptr(self._err), _lib.stream_ptr()), "render_fwd")
+        with _lib.on_device(call["ro"]):
+            key = (N, dev, prec)
+            ws = self._ws.get(key)
+            if ws is None:
+                nb = C.c_size_t()
+                _lib.check(L.emap_render_workspace_bytes(C.byref(cfg), prec, C.byref(p), C.byref(nb)), "render_workspace_bytes")
+                ws = torch.empty(nb.value, dtype=torch.uint8, device=dev)
+                self._ws = {key: ws}
+            if self._err is None or self._err.device != dev:
+                self._err = torch.zeros(1, dtype=torch.int32, device=dev)
+            co = _lib.CompositeOut()
+            names = ("edge", "depth", "weight_sum", "normals", "scalars") if reduced else \
+                _PER_SAMPLE + ("gradients_flip", "edge", "depth", "weight_sum", "normals", "scalars")
+            for k in names:
+                setattr(co, k, v[k].data_ptr())
+            packed = net.packed(call["prec_name"])
+            _lib.check(L.emap_render_fwd(C.byref(cfg), _lib.ptr(packed), prec, C.byref(p), _lib.ptr(call["ro"]), _lib.ptr(call["rd"]),
+                                         _lib.ptr(call["near"]), _lib.ptr(call["far"]), _lib.ptr(call["t_rand"]), _lib.ptr(call["ds"]),
+                                         _lib.ptr(v["z_vals"]), _lib.ptr(v["udf"]), _lib.ptr(v["gradients"]), C.byref(co), _lib.ptr(ws),
+                                         ws.numel(), _lib.ptr(self._err), _lib.stream_ptr(dev)), "render_fwd")
+        v["_ws"] = ws
+        return v
 
+    def backward_into(self, call, v, d_edge, d_depth=None, d_ge=None, d_ge_ns=None, flat=None, scalars=None, grad_scale=1.0):
+        """One emap_render_bwd call: parameter gradients of  sum(d_edge*edge) + sum(d_depth*depth) + d_ge*gradient_error +
+        d_ge_ns*gradient_error_near_surface  into `flat` (parameters() order of the UDF network, then variance, beta,
+        gamma; allocated when None).  `scalars`: the forward's scalars, or a copy with GLOBAL eikonal mask sums in [4],[6]
+        (data-parallel).  Returns flat."""
+        N, S, dev = call["N"], call["S"], call["dev"]
+        net = self.udf_network
+        lay = self._layout()
+        lay.check()
+        prec = _lib.PRECISIONS[call["prec_name"]]
+        if flat is None:
+            flat = torch.empty(lay.numel, dtype=torch.float32, device=dev)
+        f = lambda t, n: None if t is None else _lib.f32c(t.detach().reshape(-1).expand(n))
+        de, dd, dge, dns = f(d_edge, N), f(d_depth, N), f(d_ge, 1), f(d_ge_ns, 1)
+        cg = _lib.CompositeGrads()
+        cg.d_edge, cg.d_depth = (None if de is None else de.data_ptr()), (None if dd is None else dd.data_ptr())
+        cg.d_gradient_error = None if dge is None else dge.data_ptr()
+        cg.d_gradient_error_near_surface = None if dns is None else dns.data_ptr()
+        sc = v["scalars"] if scalars is None else scalars
+        cg.scalars = sc.data_ptr()
+        es = flat.element_size()
+        extra = lay.extra
+        cg.d_variance = flat.data_ptr() + es * lay.offsets[id(extra[0])]
+        cg.d_beta = flat.data_ptr() + es * lay.offsets[id(extra[1])]
+        cg.d_gamma = flat.data_ptr() + es * lay.offsets[id(extra[2])]
+        flat[lay.offsets[id(extra[0])]:].zero_()   # second_variance / zeta / unused scalar slots (tiny)
+        cg.grad_scale = float(grad_scale)
+        cg.accumulate = 0
+        pg, keep = lay.tables(flat)
+        pg.grad_scale = float(grad_scale)
+        p = call["p"]
+        L = _lib.lib()
+        cfg = net.net_config()
+        with _lib.on_device(call["ro"]):
+            nb = C.c_size_t()
+            _lib.check(L.emap_render_bwd_workspace_bytes(C.byref(cfg), prec, C.byref(p), C.byref(nb)), "render_bwd_workspace_bytes")
+            ws = _workspace(self._bws, (N, S, prec), nb.value, dev)
+            _lib.check(L.emap_render_bwd(C.byref(cfg), _lib.ptr(net.packed(call["prec_name"])), prec, C.byref(p), _lib.ptr(call["ro"]),
+                                         _lib.ptr(call["rd"]), _lib.ptr(call["ds"]), _lib.ptr(v["z_vals"]), _lib.ptr(v["udf"]),
+                                         _lib.ptr(v["gradients"]), _lib.ptr(v["_ws"]), C.byref(cg), C.byref(pg), _lib.ptr(ws),
+                                         ws.numel(), _lib.ptr(self._err), _lib.stream_ptr(dev)), "render_bwd")
+        return flat
+
+    def _trainable(self):
+        ps = list(self.udf_network.parameters()) + [self.deviation_network.variance, self.beta_network.beta, self.beta_network.gamma]
+        return torch.is_grad_enabled() and any(q.requires_grad for q in ps)
+
+    def render(self, rays_o, rays_d, near, far, depth_scale, cos_anneal_ratio=None, perturb_overwrite=-1,
+               background_rgb=None, flip_saturation=0, color_maps=None, pose=None, fx=None, fy=None, img_index=None,
+               rays_uv=None, t_rand=None):
+        """reference udf_renderer_blending.py:679-800.  Extra keyword `t_rand` ((N,1) in [-0.5,0.5)) injects
+        the jitter draw (tests); otherwise it is drawn exactly like the reference: torch.rand([N,1]) on the
+        CPU generator (:719)."""
+        call = self._prepare(rays_o, rays_d, near, far, depth_scale, cos_anneal_ratio, perturb_overwrite, background_rgb,
+                             flip_saturation, t_rand)
+        N, S, dev = call["N"], call["S"], call["dev"]
+        train = self._trainable()
+        if train:
+            lay = self._layout()
+            res = RenderFn.apply(self, call, *lay.tensors)
+            v = call["_v"]
+        else:
+            v = self._render_hip(call)
         out = {
             "udf": v["udf"].view(N, S), "edge": v["edge"].view(N, 1), "weights": v["weights"].view(N, S),
             "depth": v["depth"].view(N, 1), "gradient_error": v["scalars"][0], "gradient_error_near_surface": v["scalars"][1],
@@ -170,28 +265,17 @@ class UDFRendererBlending:
             "gradients_flip": v["gradients_flip"].view(N, S, 3), "gradient_mag": v["gradient_mag"].view(N, S),
             "weight_sum": v["weight_sum"].view(N, 1),
         }
-        z_vals = v["z_vals"].view(N, S)
-
-        params = [q for q in list(net.parameters()) + [self.deviation_network.variance, self.beta_network.beta,
-                                                       self.beta_network.gamma]]
-        if torch.is_grad_enabled() and any(q.requires_grad for q in params):
-            # INTERIM backward (SURVEY par. 8 f1): see emap_amd/_interim_backward.py
-            sample_dist = ((far_t - near_t) / self.n_samples).mean()
-            bg = None if background_rgb is None else torch.as_tensor(background_rgb, device=dev, dtype=torch.float32)
-            dsv = ds.view(N, 1) if ds is not None else torch.ones(N, 1, device=dev)
-            res = RenderCoreInterim.apply(self, ro, rd, z_vals, sample_dist, cos_anneal_ratio, bg, float(flip_saturation),
-                                          dsv, len(params), *params, *[out[k] for k in DIFF_KEYS])
-            out.update(dict(zip(DIFF_KEYS, res)))
-
+        if train:
+            out.update(dict(zip(RenderFn.DIFF + RenderFn.GUARDED, res)))
         sc = v["scalars"]
-        if torch.is_grad_enabled() and any(q.requires_grad for q in params[-3:]):
+        if train and any(q.requires_grad for q in self._layout().extra):
             # differentiable w.r.t. variance/beta/gamma: ordinary torch expressions (:466-472,656-658)
             inv_s = self.deviation_network(torch.zeros([1, 3], device=dev))[:, :1].clip(1e-6, 1e6)
             s_val = (1.0 / inv_s).expand(N * S, 1)
             beta_out = 1.0 / self.beta_network.get_beta().clip(1e-6, 1e6)
             gamma_out = self.beta_network.get_gamma().clip(1e-6, 1e6)
         else:
-            # inference: the same three numbers, written by the compositing kernel (no extra launches)
+            # the same three numbers, written by the compositing kernel (no extra launches)
             s_val = sc[8:9].view(1, 1).expand(N * S, 1)
             beta_out = sc[9:10]
             gamma_out = sc[10:11]
@@ -204,6 +288,17 @@ class UDFRendererBlending:
             "inside_sphere": v["inside_sphere"].view(N, S), "gradient_mag": out["gradient_mag"],
             "mid_z_vals": v["mid_z"].view(N, S), "dists": v["dists"].view(N, S),
             # extras (not in the reference dict)
-            "z_vals": z_vals, "alpha": v["alpha"].view(N, S), "sparse_error": v["scalars"][2],
+            "z_vals": v["z_vals"].view(N, S), "alpha": v["alpha"].view(N, S), "sparse_error": v["scalars"][2],
             "eikonal_sums": v["scalars"][3:7],
         }
+
+    def render_reduced(self, rays_o, rays_d, near, far, depth_scale, cos_anneal_ratio=None, perturb_overwrite=-1,
+                       background_rgb=None, flip_saturation=0, t_rand=None):
+        """Inference-only render that writes just the per-ray results (edge, depth, normals, weight_sum): the launch mode of
+        the full-image path (reference runner_udf.py:297-407 consumes only per-ray sums of the per-sample entries)."""
+        call = self._prepare(rays_o, rays_d, near, far, depth_scale, cos_anneal_ratio, perturb_overwrite, background_rgb,
+                             flip_saturation, t_rand, reduced=True)
+        v = self._render_hip(call)
+        N = call["N"]
+        return {"edge": v["edge"].view(N, 1), "depth": v["depth"].view(N, 1), "normals": v["normals"].view(N, 3),
+                "weight_sum": v["weight_sum"].view(N, 1), "gradient_error": v["scalars"][0], "sparse_error": v["scalars"][2]}

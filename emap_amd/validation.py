@@ -3,7 +3,9 @@
 The reference splits the H*W rays of an image into ``batch_size`` chunks, calls ``renderer.render`` per chunk and copies
 ``edge``, ``depth`` and the weighted normal ``sum_s gradients_flip * weights`` of every chunk to the host (three
 ``.detach().cpu().numpy()`` round trips per chunk).  Here the same quantities are produced by launches of ``launch_rays`` rays
-(default 8192: every MLP pass fills the chip), stay on the device and are copied to the host once.  The per-chunk jitter
+(default 8192: every MLP pass fills the chip) in the renderer's REDUCED output mode - the compositing kernel is handed NULL
+for every per-sample output and writes only edge, depth, the weighted normal and weight_sum: 28 B per ray instead of the
+48 B per sample of the training dict - stay on the device and are copied to the host once.  The per-chunk jitter
 draws of the reference (``torch.rand([chunk, 1])`` on the CPU generator, udf_renderer_blending.py:719) are reproduced in the
 same order, so with the same seed the image is the reference's image.  Rays are independent, so the result does not depend
 on how they are grouped into launches (tests/test_gpu_parity.py::test_image_render_is_chunk_invariant).
@@ -30,9 +32,9 @@ def render_image(renderer, rays_o, rays_d, near, far, depth_scale, batch_size, c
             t = slice(h, min(h + launch_rays, n))
             nr = near[t] if isinstance(near, torch.Tensor) and near.numel() > 1 else near
             fr = far[t] if isinstance(far, torch.Tensor) and far.numel() > 1 else far
-            out = renderer.render(ro[t], rd[t], nr, fr, depth_scale=ds[t], cos_anneal_ratio=cos_anneal_ratio,
-                                  background_rgb=background_rgb, perturb_overwrite=-1 if t_rand is not None else 0,
-                                  t_rand=None if t_rand is None else t_rand[t])
+            out = renderer.render_reduced(ro[t], rd[t], nr, fr, depth_scale=ds[t], cos_anneal_ratio=cos_anneal_ratio,
+                                          background_rgb=background_rgb, perturb_overwrite=-1 if t_rand is not None else 0,
+                                          t_rand=None if t_rand is None else t_rand[t])
             edge.append(out["edge"])
             depth.append(out["depth"])
             normals.append(out["normals"])        # = (gradients_flip * weights[:, :S, None]).sum(1), render_core :662

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EMAP_ABI_VERSION 1
+#define EMAP_ABI_VERSION 2
 
 /* error codes */
 #define EMAP_OK 0
@@ -83,8 +83,11 @@ int emap_pack_weights(const EmapNetConfig* cfg, const float* const* g_host, cons
  * emap_embed        : Embedder.embed                   (embedder.py:34-35)     x (P,3) -> (P,3+6L) */
 int emap_udf_fwd(const EmapNetConfig* cfg, const void* packed, int prec, const float* x, int64_t P,
                  float* udf, void* stream);
+/* scratch: device buffer of emap_udf_scratch_bytes() bytes (0 for small launches; the reverse-mode kernel keeps its
+ * per-workgroup sigma' slabs there); may be NULL when that size is 0 */
+int emap_udf_scratch_bytes(const EmapNetConfig* cfg, int prec, int64_t P, size_t* bytes);
 int emap_udf_fwd_grad(const EmapNetConfig* cfg, const void* packed, int prec, const float* x, int64_t P,
-                      float* udf, float* grad3, void* stream);
+                      float* udf, float* grad3, void* scratch, size_t scratch_bytes, void* stream);
 int emap_embed(const float* x, int64_t P, int multires, float* pe, void* stream);
 
 /* ---- sampler -------------------------------------------------------------------------------
@@ -172,12 +175,71 @@ int emap_composite_fwd_p(const float* rays_o, const float* rays_d, const float* 
                          const EmapRenderParams* p, const EmapCompositeOut* out, float* partials,
                          int32_t* err_flags, void* stream);
 
-int emap_render_workspace_bytes(const EmapRenderParams* p, size_t* bytes);
+int emap_render_workspace_bytes(const EmapNetConfig* cfg, int prec, const EmapRenderParams* p, size_t* bytes);
 int emap_render_fwd(const EmapNetConfig* cfg, const void* packed, int prec, const EmapRenderParams* p,
                     const float* rays_o, const float* rays_d, const float* near, const float* far,
                     const float* t_rand, const float* depth_scale, float* z_vals, float* udf, float* grad3,
                     const EmapCompositeOut* out, void* workspace, size_t workspace_bytes, int32_t* err_flags,
                     void* stream);
+
+/* ---- training backward (SURVEY par. 8 f1) --------------------------------------------------------
+ * Replaces torch.autograd through render_core and UDFNetwork.gradient(create_graph=True) under loss.backward()
+ * (udf_renderer_blending.py:457-625, udf_model.py:121-135, runner_udf.py:166-167).  importance_sample is @torch.no_grad
+ * and z_samples are detached (udf_renderer_blending.py:344,802), so parameters receive gradient only through the final
+ * (udf, grad_x udf) evaluation at the sample points and through inv_s / beta / gamma:
+ *
+ * emap_composite_bwd : dL/d{edge, depth, gradient_error, gradient_error_near_surface}  ->  dL/dudf (N,S),
+ *                      dL/d(grad_x udf) (N,S,3), dL/d{variance, beta, gamma}
+ * emap_udf_vjp       : (dL/dudf (P), dL/dgrad (P,3)) at points x (P,3)  ->  dL/d{g_l, v_l, bias_l} of every Linear
+ *                      (the double backward incl. Softplus'', skip concat, |.|, and the weight-norm VJP)
+ * emap_render_bwd    : both, for the z_vals / udf / grad3 that emap_render_fwd returned
+ *
+ * Gradient outputs are written (accumulate = 0) or added to (accumulate = 1) and multiplied by grad_scale.
+ * The pointer tables are HOST arrays of n_lin device pointers with the shapes of emap_pack_weights
+ * (g [out,1], v [out,in], bias [out]); dg_host may be NULL when weight_norm = 0 (then dv = dL/dW). */
+typedef struct EmapCompositeGrads {
+    const float* d_edge;                         /* (N) or NULL                                  */
+    const float* d_depth;                        /* (N) or NULL (gradient of the depth_scale'd depth) */
+    const float* d_gradient_error;               /* device scalar or NULL                        */
+    const float* d_gradient_error_near_surface;  /* device scalar or NULL                        */
+    const float* scalars;                        /* EmapCompositeOut.scalars of the forward ([4], [6] = the eikonal mask sums;
+                                                    data-parallel callers put the GLOBAL sums there) */
+    float* d_variance;                           /* out (1) or NULL: dL/d SingleVarianceNetwork.variance */
+    float* d_beta;                               /* out (1) or NULL: dL/d BetaNetwork.beta       */
+    float* d_gamma;                              /* out (1) or NULL: dL/d BetaNetwork.gamma      */
+    float grad_scale;
+    int32_t accumulate;
+} EmapCompositeGrads;
+
+typedef struct EmapParamGrads {
+    const float* const* g_host;   /* parameters (for the weight-norm VJP) */
+    const float* const* v_host;
+    float* const* dg_host;        /* outputs */
+    float* const* dv_host;
+    float* const* db_host;
+    int32_t weight_norm;          /* 1: W = g v/||v|| (udf_model.py:73-74); 0: W = v */
+    int32_t accumulate;
+    float grad_scale;
+    int32_t reserved;
+} EmapParamGrads;
+
+/* partials: (N,4) scratch.  With variance_dev == NULL in `p` the three scalar outputs are dL/d{inv_s, beta, gamma}. */
+int emap_composite_bwd(const float* rays_o, const float* rays_d, const float* z, const float* udf, const float* grad3,
+                       const float* depth_scale, int N, int S, const float* sample_dist_dev, const EmapRenderParams* p,
+                       const EmapCompositeGrads* g, float* d_udf, float* d_grad3, float* partials, void* stream);
+
+int emap_udf_vjp_workspace_bytes(const EmapNetConfig* cfg, int prec, int64_t P, size_t* bytes);
+int emap_udf_vjp(const EmapNetConfig* cfg, const void* packed, int prec, const float* x, int64_t P, const float* d_udf,
+                 const float* d_grad3, const EmapParamGrads* out, void* workspace, size_t workspace_bytes,
+                 int32_t* err_flags, void* stream);
+
+/* z_vals (N,S), udf (N,S), grad3 (N,S,3), sample_dist_dev: what emap_render_fwd produced (sample_dist_dev = the first
+ * float of its workspace).  workspace: emap_render_bwd_workspace_bytes(). */
+int emap_render_bwd_workspace_bytes(const EmapNetConfig* cfg, int prec, const EmapRenderParams* p, size_t* bytes);
+int emap_render_bwd(const EmapNetConfig* cfg, const void* packed, int prec, const EmapRenderParams* p, const float* rays_o,
+                    const float* rays_d, const float* depth_scale, const float* z_vals, const float* udf, const float* grad3,
+                    const float* sample_dist_dev, const EmapCompositeGrads* g, const EmapParamGrads* out, void* workspace,
+                    size_t workspace_bytes, int32_t* err_flags, void* stream);
 
 /* ---- dense-grid extraction (SURVEY par. 8 f2) ----------------------------------------------------
  * emap_null_direction : `_, _, vh = torch.linalg.svd(grad_ld); F.normalize(vh[:, -1, :])` of get_udf_normals_grid /

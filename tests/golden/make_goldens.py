@@ -235,6 +235,15 @@ def g6_training():
         true_edge = synthetic.make_true_edge(N, seed=30 + ci)
         r, dev, bet = make_renderer(net, ns, ni, steps)
         loss_fn = EdgeLoss("mse")
+        zs = []
+        orig = r.cat_z_vals
+
+        def rec_cat(*a, _orig=orig, _zs=zs, **k):
+            z, u = _orig(*a, **k)
+            _zs.append(z.detach().clone())
+            return z, u
+
+        r.cat_z_vals = rec_cat
         out = r.render(rays_o, rays_d, near, far, depth_scale, cos_anneal_ratio=car, perturb_overwrite=0,
                        flip_saturation=fs)
         edge_weight, igr_weight, igr_ns_weight = 1.0, 0.1, 0.05
@@ -249,7 +258,9 @@ def g6_training():
              "loss": loss.detach(), "edge_loss": edge_loss.detach(), "edge": out["edge"].detach(),
              "gradient_error": out["gradient_error"].detach(),
              "gradient_error_near_surface": out["gradient_error_near_surface"].detach(),
-             "netname": np.array(netname)}
+             "netname": np.array(netname),
+             # the samples the reference differentiated at (importance_sample is @no_grad, :802) and what it saw there
+             "z_vals": zs[-1], "udf": out["udf"].detach(), "gradients": out["gradients"].detach()}
         for k, p in net.named_parameters():
             d["grad." + k] = p.grad if p.grad is not None else torch.zeros_like(p)
         d["grad.variance"] = dev.variance.grad if dev.variance.grad is not None else torch.zeros(1)
