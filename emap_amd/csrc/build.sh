@@ -15,6 +15,6 @@ for f in udf_mlp udf_mlp_bf16 udf_mlp_bf16x3 udf_mlp_f16 udf_mlp_f16x3 sampler e
 done
 for p in "${pids[@]}"; do wait $p; done
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT/libemap_hip.so $OUT/udf_mlp.o $OUT/udf_mlp_bf16.o $OUT/udf_mlp_bf16x3.o $OUT/udf_mlp_f16.o $OUT/udf_mlp_f16x3.o $OUT/sampler.o $OUT/extraction.o $OUT/wgrad.o $OUT/api.o
-python3 ../../scripts/isa_lint.py $OUT/isa/udf_mlp_*gfx950*.s
+python3 ../../scripts/isa_lint.py $OUT/isa/udf_mlp_*gfx950*.s $OUT/isa/wgrad*gfx950*.s
 find $OUT/isa -type f ! -name "*gfx950*.s" -delete   # keep only the device assembly
 echo "built $OUT/libemap_hip.so"

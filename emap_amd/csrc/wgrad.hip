@@ -13,6 +13,8 @@
 //   absmax_kernel  : max|du|, max|dg| of a launch (the range scale K of the sweep).
 #include "emap_common.h"
 #include <string.h>
+#include <type_traits>
+#include <utility>
 
 namespace emap {
 
@@ -54,47 +56,98 @@ struct WgradArgs {
     WgradJob job[WGRAD_MAX_JOBS];
 };
 
+// The K loop is software-pipelined by hand with the same device the MLP kernels use (inline-asm loads retired by counted
+// s_waitcnt vmcnt(N) statements that name their destination registers; hipcc otherwise sinks every load to its first use and
+// the loop runs at one HBM latency per fragment: measured 1.8 ms instead of 0.3 ms for 65 536 points).  A step = one K-step
+// of one tile (2 Z fragments + CT A fragments).  Every A register is reloaded for the NEXT step right after the two MFMAs that
+// consumed it and the next step's Z fragments are issued at the top of the step, so CT + 2 coalesced 1 KiB loads per wave are in
+// flight at all times.  In-flight order at the top of a step: Z0, Z1, A[0..CT-1]  ->  vmcnt(CT-1) retires Z and A[0]; inside
+// the step A[c] has CT+1 younger loads behind it.  Column tiles beyond a_ct and a missing second row tile are clamped to valid
+// addresses: their accumulators are garbage and never stored.  scripts/isa_lint.py checks the register discipline.
 template <class V8>
-__global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgradArgs a) {
-    int ji = 0;
-    while (ji + 1 < a.n_jobs && (int)blockIdx.x >= a.job[ji + 1].first_wg) ++ji;
-    const WgradJob J = a.job[ji];
-    const int slice = (int)blockIdx.x - J.first_wg;
+__device__ __forceinline__ void wg_load(V8& dst, int voff, const char* sbase) {
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");   // s_nop: see asm_gload16
+}
+template <int N, class V8>
+__device__ __forceinline__ void wg_wait(V8& r0) { asm volatile("s_waitcnt vmcnt(%c1)" : "+v"(r0) : "i"(N) : "memory"); }
+template <int N, class V8>
+__device__ __forceinline__ void wg_wait3(V8& r0, V8& r1, V8& r2) { asm volatile("s_waitcnt vmcnt(%c3)" : "+v"(r0), "+v"(r1), "+v"(r2) : "i"(N) : "memory"); }
+__device__ __forceinline__ const char* wg_uniform(const char* p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
+}
+
+template <int... Is, class F>
+__device__ __forceinline__ void wg_static_for_impl(std::integer_sequence<int, Is...>, F&& f) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void wg_static_for(F&& f) { wg_static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f)); }
+
+template <class V8, int NB>
+__device__ __forceinline__ void wgrad_run(const WgradArgs& a, const WgradJob& J, int slice, int wave, int lane) {
+    constexpr int CT = 4 * NB;
     const int t0 = (int)(((long long)a.n_tiles * slice) / J.n_slices), t1 = (int)(((long long)a.n_tiles * (slice + 1)) / J.n_slices);
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nrt = (wave < J.z_rt ? 1 : 0) + (wave + 8 < J.z_rt ? 1 : 0);
-    constexpr int CTM = 16;
-    f32x4 acc[2][CTM];
+    f32x4 acc[2][CT];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int c = 0; c < CTM; ++c) acc[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < CT; ++c) acc[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
     float bsum[2] = {0.f, 0.f};
-    if (nrt > 0) {
-        const char* zb = a.stash_z + (size_t)J.z_off * 1024 + (size_t)wave * 2048 + lane * 16;
-        const char* ab = a.stash_a + (size_t)J.a_off * 1024 + lane * 16;
-        for (int tile = t0; tile < t1; ++tile) {
-            const char* zt = zb + (size_t)tile * ((size_t)a.z_tile_kb * 1024);
-            const char* at = ab + (size_t)tile * ((size_t)a.a_tile_kb * 1024);
+    if (nrt > 0 && t1 > t0) {
+        const size_t zts = (size_t)a.z_tile_kb * 1024, ats = (size_t)a.a_tile_kb * 1024;
+        const char* zb = wg_uniform(a.stash_z + (size_t)J.z_off * 1024 + (size_t)wave * 2048);
+        const char* ab = wg_uniform(a.stash_a + (size_t)J.a_off * 1024);
+        const int z1 = (nrt > 1) ? 8 * 2048 : 0;
+        const int voff = lane * 16;
+        constexpr int R = (CT >= 8) ? CT / 2 : CT;   // prefetch ring: fragments in flight per wave
+        V8 af[R], za[2], zb2[2];
+        auto ldz = [&](V8 (&z)[2], int tile, int s) __attribute__((always_inline)) {
+            const char* b = zb + (size_t)tile * zts + s * 1024;
+            wg_load(z[0], voff, b);
+            wg_load(z[1], voff, b + z1);
+        };
+        // NT tiles = 2*NT steps of straight-line code: prologue loads, steps that prefetch R fragments ahead, a last step that
+        // drains - no load is in flight across a loop back-edge (the compiler would otherwise be free to copy such registers).
+        // A fragment (u, c) lives in ring slot c % R (R divides CT).  Loads younger than A(u, c) when it is needed:
+        //   c == 0: R-1 (the wait also retires Z(u), issued a step earlier);  0 < c < R: R+1 (Z(u+1) was issued in between);
+        //   c >= R: R-1;  in the last step nothing is issued any more: min(R-1, CT-1-c).
+        auto block = [&](auto nt_c, int tb) __attribute__((always_inline)) {
+            constexpr int NT = decltype(nt_c)::value;
+            ldz(za, tb, 0);
+            {
+                const char* a0 = ab + (size_t)tb * ats;
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                V8 zf[2];
-                zf[0] = *reinterpret_cast<const V8*>(zt + s * 1024);
-                zf[1] = (nrt > 1) ? *reinterpret_cast<const V8*>(zt + 8 * 2048 + s * 1024) : V8{};
+                for (int c = 0; c < R; ++c) wg_load(af[c], voff, a0 + (c < J.a_ct ? c : J.a_ct - 1) * 2048);
+            }
+            wg_static_for<2 * NT>([&](auto u_c) __attribute__((always_inline)) {
+                constexpr int u = decltype(u_c)::value;
+                constexpr bool LAST = (u == 2 * NT - 1);
+                V8 (&zc)[2] = (u & 1) ? zb2 : za;
+                V8 (&zn)[2] = (u & 1) ? za : zb2;
+                wg_wait3<R - 1>(zc[0], zc[1], af[0]);
+                const int ntile = tb + ((u + 1) >> 1), ns = (u + 1) & 1;
+                if constexpr (!LAST) ldz(zn, ntile, ns);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)   // value columns are K slots e with e % 4 < 2
-                    bsum[i] += ((float)zf[i][0] + (float)zf[i][1]) + ((float)zf[i][4] + (float)zf[i][5]);
-#pragma unroll
-                for (int c = 0; c < CTM; ++c) {
-                    if (c < J.a_ct) {
-                        const V8 af = *reinterpret_cast<const V8*>(at + c * 2048 + s * 1024);
-                        acc[0][c] = mfma16w(zf[0], af, acc[0][c]);
-                        acc[1][c] = mfma16w(zf[1], af, acc[1][c]);
-                    }
-                }
-            }
-        }
+                    bsum[i] += ((float)zc[i][0] + (float)zc[i][1]) + ((float)zc[i][4] + (float)zc[i][5]);
+                const char* ac = ab + (size_t)(tb + (u >> 1)) * ats + (u & 1) * 1024;
+                const char* an = ab + (size_t)ntile * ats + ns * 1024;
+                wg_static_for<CT>([&](auto c_c) __attribute__((always_inline)) {
+                    constexpr int c = decltype(c_c)::value;
+                    constexpr int lastY = (R - 1 < CT - 1 - c) ? R - 1 : CT - 1 - c;
+                    if constexpr (c > 0) wg_wait<LAST ? lastY : (c < R ? R + 1 : R - 1)>(af[c % R]);
+                    acc[0][c] = mfma16w(zc[0], af[c % R], acc[0][c]);
+                    acc[1][c] = mfma16w(zc[1], af[c % R], acc[1][c]);
+                    constexpr int cn = (c + R) % CT;                       // the fragment R ahead: same step or the next one
+                    if constexpr (c + R < CT) wg_load(af[c % R], voff, ac + (cn < J.a_ct ? cn : J.a_ct - 1) * 2048);
+                    else if constexpr (!LAST) wg_load(af[c % R], voff, an + (cn < J.a_ct ? cn : J.a_ct - 1) * 2048);
+                });
+            });
+        };
+        int tile = t0;
+        for (; tile + 4 <= t1; tile += 4) block(std::integral_constant<int, 4>{}, tile);
+        for (; tile < t1; ++tile) block(std::integral_constant<int, 1>{}, tile);
     }
     // partial block [slice][row tile 0..15][a_ct][64 lanes x 4]
     float* pb = a.partial + J.part_off + (size_t)slice * 16 * J.a_ct * 256;
@@ -103,7 +156,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgradArgs a) {
         const int rt = wave + 8 * i;
         if (rt < J.z_rt) {
 #pragma unroll
-            for (int c = 0; c < CTM; ++c) {
+            for (int c = 0; c < CT; ++c) {
                 if (c < J.a_ct) {
                     f32x4* dst = reinterpret_cast<f32x4*>(pb + ((size_t)rt * J.a_ct + c) * 256 + lane * 4);
                     *dst = a.accumulate ? (*dst + acc[i][c]) : acc[i][c];
@@ -124,6 +177,21 @@ __global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgradArgs a) {
             }
         }
     }
+}
+
+template <class V8>
+__global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgradArgs a) {
+    int ji = 0;
+    while (ji + 1 < a.n_jobs && (int)blockIdx.x >= a.job[ji + 1].first_wg) ++ji;
+    const WgradJob J = a.job[ji];
+    const int slice = (int)blockIdx.x - J.first_wg;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nb = (J.a_ct + 3) >> 2;
+    if (nb <= 1) wgrad_run<V8, 1>(a, J, slice, wave, lane);
+    else if (nb == 2) wgrad_run<V8, 2>(a, J, slice, wave, lane);
+    else if (nb == 3) wgrad_run<V8, 3>(a, J, slice, wave, lane);
+    else wgrad_run<V8, 4>(a, J, slice, wave, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -183,6 +251,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const ReduceArgs a) {
     const float inv_k = a.grad_scale / vjp_scale_from_w(a.absmax);
     const float mult = (l == a.skip_l) ? 0.70710678118654752440f : 1.0f;
     const int rt = o >> 4, m = o & 15;
+    // the last layer's Z level holds its single real row twice: row 0 = hi part, row 1 = lo part of the seeds (udf_mlp_vjp.inc)
+    const bool last = (l == a.n_lin - 1);
     constexpr int MAXC = 6;     // ceil((256 + 63) / 64)
     float dw[MAXC], vv[MAXC];
     float dot = 0.f, nrm = 0.f;
@@ -195,6 +265,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const ReduceArgs a) {
             float s;
             if (k < in_prev) {
                 s = partial_at(a.partial, a.job[a.job_h[l]], rt, m, k >> 4, k & 15);
+                if (last) s += partial_at(a.partial, a.job[a.job_h[l]], rt, 1, k >> 4, k & 15);
             } else {
                 // natural PE column -> slot (sp, g, e) of the PE block (udf_mlp.hip:pack_kernel) -> row tile 2*sp + e/4, row 4g + e%4
                 const int pc = k - in_prev, M = a.multires;
@@ -204,6 +275,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const ReduceArgs a) {
                 const int g = ang >> 3, qq = ang & 7, sp = qq >> 2, e = 2 * (qq & 3) + kind;
                 const int prow = 4 * g + (e & 3), ptile = 2 * sp + (e >> 2);
                 s = partial_at(a.partial, a.job[a.job_pe[l]], rt, m, ptile, prow);
+                if (last) s += partial_at(a.partial, a.job[a.job_pe[l]], rt, 1, ptile, prow);
             }
             dw[c] = s * inv_k * mult;      // d/dW_l of the reference's Linear (the packed weight holds W_l/sqrt2 for the skip layer)
             vv[c] = vrow[k];
@@ -237,7 +309,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const ReduceArgs a) {
         const int jb = (a.job_h[l] >= 0) ? a.job_h[l] : a.job_pe[l];
         const WgradJob& J = a.job[jb];
         float s = 0.f;
-        for (int q = 0; q < J.n_slices; ++q) s += a.partial[J.bias_off + (size_t)q * 256 + o];
+        for (int q = 0; q < J.n_slices; ++q) s += a.partial[J.bias_off + (size_t)q * 256 + o] + (last ? a.partial[J.bias_off + (size_t)q * 256 + 1] : 0.f);
         const float r = s * inv_k;
         a.db[l][o] = a.accumulate ? a.db[l][o] + r : r;
     }

@@ -1,18 +1,25 @@
-"""Data-parallel training step over rays: one process per GPU, ``torch.distributed`` ("nccl" == RCCL over
-xGMI on ROCm; "gloo" in the CPU tests).
+"""Data-parallel training step over rays: one process per GPU, ``torch.distributed`` ("nccl" == RCCL over xGMI on ROCm;
+"gloo" in the CPU tests).
 
-EMAP itself is single-GPU (SURVEY.md par. 2a); this is the sharding the hot path admits (par. 8e):
-rays are independent through sampling, MLP and compositing, so every rank renders its slice of ONE
-global batch with replicated weights and the only exchange is
+EMAP itself is single-GPU (SURVEY.md par. 2a); this is the sharding the hot path admits (par. 8e): rays are independent
+through sampling, MLP and compositing, so every rank renders its slice of ONE global batch with replicated weights.  The
+step arithmetic restates reference src/runner/runner_udf.py:90-168 (mask of ones, MSE * edge_weight + igr_ns_weight *
+ge_ns + igr_weight * ge, zero_grad / backward / step).
 
-  1. a 2-float all-reduce of the eikonal mask counts *before* backward (the loss's masked means
-     ``sum(m*e)/(sum(m)+1e-5)`` run over all rays of the batch, reference udf_renderer_blending.py:618-625,
-     so the denominators must be global for the result to equal the single-GPU step), and
-  2. ONE all-reduce(sum) of a flat fp32 bucket holding every parameter gradient (about 1.85 MB) after
-     backward.
+``Trainer`` is the native step (no autograd graph, no per-parameter copies):
 
-The step arithmetic restates reference src/runner/runner_udf.py:90-168 (mask of ones, MSE * edge_weight
-+ igr_ns_weight * ge_ns + igr_weight * ge, zero_grad / backward / step).
+  forward     emap_render_fwd on the rank's rays                                   (HIP, no collective)
+  stats       [sum(relax), sum(near), sum((edge-gt)^2), sum(relax*err), sum(near*err)]   5 floats
+  backward    emap_render_bwd writes dL/dtheta of the rank's share of the GLOBAL loss straight into one flat fp32 buffer laid
+              out in parameters() order - the parameters themselves are views of one flat buffer as well
+  all-reduce  ONE collective over that buffer (about 1.85 MB for d8 w256; the stats ride in its tail)
+  Adam        one fused update per parameter group on the flat buffers (torch.optim.Adam, the reference's optimizer)
+
+The eikonal terms are masked means over ALL rays of the batch (udf_renderer_blending.py:618-625): their denominators must be
+the global mask sums for the step to equal the single-GPU step.  ``eikonal_sync="exact"`` (default) therefore all-reduces the 5
+stats before the backward (20 bytes, the only other collective of the step); ``eikonal_sync="local"`` uses the rank's own
+denominators (a mean of per-rank means - exact whenever the masks cover every sample, as they do for scenes inside the unit
+sphere) and the step has exactly one collective.
 """
 from __future__ import annotations
 
@@ -30,73 +37,157 @@ def shard(t: torch.Tensor, rank: int, world: int) -> torch.Tensor:
     return t[rank * per:(rank + 1) * per].contiguous()
 
 
-class GradBucket:
-    """Flat fp32 bucket over the gradients of `params`; one all-reduce(sum) for all of them."""
+def _world(group=None) -> int:
+    return dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
 
-    def __init__(self, params: Iterable[torch.nn.Parameter]):
-        self.params: List[torch.nn.Parameter] = [p for p in params]
-        self.numel = sum(p.numel() for p in self.params)
-        self.flat: Optional[torch.Tensor] = None
 
-    def all_reduce(self, group=None):
+class FlatParams:
+    """Re-homes `params` as views of ONE flat fp32 buffer (and their .grad as views of one flat gradient buffer), so that a
+    gradient all-reduce and an optimizer step touch one tensor instead of one per parameter."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], extra: int = 0):
+        self.params: List[torch.nn.Parameter] = list(params)
         dev = self.params[0].device
-        if self.flat is None or self.flat.device != dev:
-            self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        self.numel = sum(p.numel() for p in self.params)
+        self.data = torch.empty(self.numel, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(self.numel + extra, dtype=torch.float32, device=dev)   # tail: step statistics
         off = 0
-        for p in self.params:
-            n = p.numel()
-            if p.grad is None:
-                self.flat[off:off + n].zero_()
-            else:
-                self.flat[off:off + n].copy_(p.grad.reshape(-1))
-            off += n
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            if p.requires_grad:
-                g = self.flat[off:off + n].view_as(p)
-                if p.grad is None:
-                    p.grad = g.clone()
-                else:
-                    p.grad.copy_(g)
-            off += n
+        self.offsets = {}
+        with torch.no_grad():
+            for p in self.params:
+                n = p.numel()
+                self.data[off:off + n].copy_(p.detach().reshape(-1))
+                p.data = self.data[off:off + n].view(p.shape)
+                p.grad = self.grad[off:off + n].view(p.shape)
+                self.offsets[id(p)] = off
+                off += n
+
+    def span(self, params: Iterable[torch.nn.Parameter]):
+        """(start, end) of a run of parameters that are adjacent in the flat buffer."""
+        ps = list(params)
+        s = self.offsets[id(ps[0])]
+        e = self.offsets[id(ps[-1])] + ps[-1].numel()
+        assert e - s == sum(p.numel() for p in ps), "parameters are not contiguous in the flat buffer"
+        return s, e
 
 
-def training_step(render_fn: Callable[[], Dict[str, torch.Tensor]], true_edge: torch.Tensor, params, optimizer,
+class Trainer:
+    """Native data-parallel training step of the render hot path (see the module docstring)."""
+
+    N_STATS = 8
+
+    def __init__(self, renderer, lr_geo: float = 1e-4, lr: float = 5e-4, edge_weight: float = 1.0, igr_weight: float = 0.1,
+                 igr_ns_weight: float = 0.0, group=None, eikonal_sync: str = "exact", fused_adam: Optional[bool] = None):
+        assert eikonal_sync in ("exact", "local")
+        self.r = renderer
+        self.group = group
+        self.eikonal_sync = eikonal_sync
+        self.edge_weight, self.igr_weight, self.igr_ns_weight = float(edge_weight), float(igr_weight), float(igr_ns_weight)
+        net = renderer.udf_network
+        self.geo = list(net.parameters())
+        self.scalars = [renderer.deviation_network.variance, renderer.beta_network.beta, renderer.beta_network.gamma]
+        self.flat = FlatParams(self.geo + self.scalars, extra=self.N_STATS)
+        renderer._lay = None                      # the layout caches tensor identities / pointers: rebuild on the flat views
+        lay = renderer._layout()
+        assert lay.numel == self.flat.numel and all(lay.offsets[id(p)] == self.flat.offsets[id(p)] for p in self.flat.params)
+        g0, g1 = self.flat.span(self.geo)
+        s0, s1 = self.flat.span(self.scalars)
+        # two flat "parameters" = the reference's two Adam groups (runner_base.py:110-117)
+        self.p_geo = torch.nn.Parameter(self.flat.data[g0:g1])
+        self.p_sc = torch.nn.Parameter(self.flat.data[s0:s1])
+        self.p_geo.grad = self.flat.grad[g0:g1]
+        self.p_sc.grad = self.flat.grad[s0:s1]
+        dev = self.flat.data.device
+        if fused_adam is None:
+            fused_adam = dev.type == "cuda"
+        self.optimizer = torch.optim.Adam([{"params": [self.p_geo], "lr": lr_geo}, {"params": [self.p_sc]}], lr=lr,
+                                          **({"fused": True} if fused_adam else {}))
+        self.collectives_per_step = 0 if _world(group) == 1 else (2 if eikonal_sync == "exact" else 1)
+        # "local": every rank normalises by its own mask sums, so the sum over ranks needs the 1/world of a mean of means
+        k = 1.0 / _world(group) if eikonal_sync == "local" else 1.0
+        self._igr = torch.tensor([self.igr_weight * k], device=dev)
+        self._igr_ns = torch.tensor([self.igr_ns_weight * k], device=dev)
+        self._idx = torch.tensor([4, 6, 3, 5], device=dev)
+        self.last_stats = None
+
+    # ---- the three device stages; the CPU tests substitute oracle implementations for the two HIP ones ----
+    def _forward(self, rays):
+        r = self.r
+        call = r._prepare(rays["rays_o"], rays["rays_d"], rays["near"], rays["far"], rays.get("depth_scale"), rays.get("cos_anneal_ratio"),
+                          rays.get("perturb_overwrite", -1), rays.get("background_rgb"), rays.get("flip_saturation", 0.0), rays.get("t_rand"))
+        v = r._render_hip(call)
+        return call, v, v["edge"], v["scalars"]
+
+    def _backward(self, call, v, d_edge, scalars_glob, flat_grad):
+        self.r.backward_into(call, v, d_edge, None, self._igr, self._igr_ns if self.igr_ns_weight != 0.0 else None,
+                             flat=flat_grad, scalars=scalars_glob)
+
+    def step(self, rays: Dict, true_edge: torch.Tensor, n_rays_global: Optional[int] = None):
+        """One optimizer step on this rank's rays.  Returns the device tensor [loss, edge_loss] of the GLOBAL batch (no host
+        synchronisation happens here)."""
+        world = _world(self.group)
+        call, v, edge, scalars = self._forward(rays)
+        n_local = edge.numel()
+        n_glob = n_rays_global if n_rays_global is not None else n_local * world
+        te = true_edge.reshape(-1).to(edge.dtype)
+        diff = edge.reshape(-1) - te
+        # stats: [sum(relax), sum(near), sum(relax*err), sum(near*err), sum(diff^2)] - scalars[3:7] = e_rel, c_rel, e_ns, c_ns
+        stats = torch.cat([scalars[self._idx], (diff * diff).sum().reshape(1)])
+        sc_glob = scalars
+        if world > 1 and self.eikonal_sync == "exact":
+            dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=self.group)
+            sc_glob = scalars.clone()
+            sc_glob[4], sc_glob[6] = stats[0], stats[1]
+        d_edge = diff * (2.0 * self.edge_weight / n_glob)
+        g = self.flat.grad
+        self._backward(call, v, d_edge, sc_glob, g[:self.flat.numel])
+        if world > 1:
+            if self.eikonal_sync == "local":
+                g[self.flat.numel:self.flat.numel + 5] = stats      # the statistics ride in the bucket's tail
+            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+            if self.eikonal_sync == "local":
+                stats = g[self.flat.numel:self.flat.numel + 5].clone()
+        self.optimizer.step()
+        self.r.udf_network.invalidate_packed()   # the flat update does not bump the per-parameter version counters
+        edge_loss = stats[4] / n_glob * self.edge_weight
+        loss = edge_loss + self.igr_weight * stats[2] / (stats[0] + 1e-5) + self.igr_ns_weight * stats[3] / (stats[1] + 1e-5)
+        self.last_stats = torch.stack([loss, edge_loss])
+        return self.last_stats
+
+
+# ---------------------------------------------------------------------------------------------
+# generic autograd-based step (any differentiable render_fn; used with the drop-in classes and by the CPU tests)
+# ---------------------------------------------------------------------------------------------
+def training_step(render_fn: Callable[[], Dict[str, torch.Tensor]], true_edge: torch.Tensor, flat: FlatParams, optimizer,
                   edge_weight: float = 1.0, igr_weight: float = 0.1, igr_ns_weight: float = 0.0, group=None,
-                  bucket: Optional[GradBucket] = None, n_rays_global: Optional[int] = None):
-    """One optimizer step on this rank's ray shard; equals the single-GPU step on the global batch.
+                  n_rays_global: Optional[int] = None):
+    """One optimizer step on this rank's ray shard through autograd; equals the single-process step on the global batch.
 
-    render_fn() -> render dict for this rank's rays (must contain "edge", "gradient_error",
-    "gradient_error_near_surface" and "eikonal_sums" = [sum(relax*err), sum(relax), sum(near*err), sum(near)]).
-    Returns (loss_global, edge_loss_global) as detached 0-d tensors (identical on every rank).
-    """
-    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+    render_fn() -> render dict for this rank's rays (must contain "edge", "gradient_error", "gradient_error_near_surface" and
+    "eikonal_sums" = [sum(relax*err), sum(relax), sum(near*err), sum(near)]).  `flat` holds the parameters (FlatParams): the
+    gradients accumulate into its flat buffer and ONE all-reduce covers them.  Returns (loss_global, edge_loss_global)."""
+    world = _world(group)
     out = render_fn()
     edge = out["edge"]
     n_local = edge.shape[0]
     n_glob = n_rays_global if n_rays_global is not None else n_local * world
     sums = out["eikonal_sums"].detach()
-    counts = torch.stack([sums[1], sums[3]]).to(torch.float32)  # local denominators (no gradient)
-    counts_glob = counts.clone()
-    if world > 1:
-        dist.all_reduce(counts_glob, op=dist.ReduceOp.SUM, group=group)
-    # local numerators with gradient: ge_local * (c_local + 1e-5)
-    e_rel = out["gradient_error"] * (counts[0] + 1e-5)
-    e_ns = out["gradient_error_near_surface"] * (counts[1] + 1e-5)
     mse_sum = ((edge - true_edge) ** 2).sum()
-    n_elem_glob = n_glob * (edge.numel() // n_local)
-    loss_local = mse_sum / n_elem_glob * edge_weight \
-        + e_ns / (counts_glob[1] + 1e-5) * igr_ns_weight + e_rel / (counts_glob[0] + 1e-5) * igr_weight
-    optimizer.zero_grad()
-    loss_local.backward()
-    if bucket is None:
-        bucket = GradBucket(params)
-    bucket.all_reduce(group)
-    optimizer.step()
-    stats = torch.stack([loss_local.detach(), (mse_sum / n_elem_glob * edge_weight).detach()])
+    stats = torch.stack([sums[1], sums[3], mse_sum.detach(), sums[0], sums[2]]).to(torch.float32)
     if world > 1:
-        dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
-    return stats[0], stats[1]
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)   # global mask counts before backward (+ the loss statistics)
+    # local numerators with gradient: ge_local * (c_local + 1e-5)
+    e_rel = out["gradient_error"] * (sums[1] + 1e-5)
+    e_ns = out["gradient_error_near_surface"] * (sums[3] + 1e-5)
+    n_elem_glob = n_glob * (edge.numel() // n_local)
+    loss_local = mse_sum / n_elem_glob * edge_weight + e_ns / (stats[1] + 1e-5) * igr_ns_weight + e_rel / (stats[0] + 1e-5) * igr_weight
+    flat.grad.zero_()
+    for p in flat.params:
+        p.grad = flat.grad[flat.offsets[id(p)]:flat.offsets[id(p)] + p.numel()].view(p.shape)   # autograd accumulates in place
+    loss_local.backward()
+    if world > 1:
+        dist.all_reduce(flat.grad, op=dist.ReduceOp.SUM, group=group)
+    optimizer.step()
+    edge_loss = stats[2] / n_elem_glob * edge_weight
+    loss = edge_loss + igr_weight * stats[3] / (stats[0] + 1e-5) + igr_ns_weight * stats[4] / (stats[1] + 1e-5)
+    return loss, edge_loss

@@ -68,7 +68,7 @@ def _cmp(got, ref, tol, what=""):
     return worst
 
 
-TOL = {"f16x3": 1e-3, "bf16x3": 3e-3, "f16": 3e-2, "bf16": 1.5e-1}
+TOL = {"f16x3": 1e-3, "bf16x3": 8e-3, "f16": 3e-2, "bf16": 1.5e-1}
 
 
 @pytest.mark.parametrize("name,prec,scale,ut", [("d8w256L10", "f16x3", 1.0, "abs"), ("d4w128L10", "f16x3", 1.0, "abs"),
@@ -228,7 +228,7 @@ def test_render_bwd_on_reference_samples_vs_reference_gradients(ci):
         assert abs(float(extra[k]) - r_) <= 1e-3 * abs(r_) + 1e-6 * gmax, (k, float(extra[k]), r_)
 
 
-@pytest.mark.parametrize("prec,tol", [("bf16x3", 5e-3), ("f16", 5e-2), ("bf16", 3e-1)])
+@pytest.mark.parametrize("prec,tol", [("bf16x3", 1e-2), ("f16", 5e-2), ("bf16", 3e-1)])
 def test_render_bwd_throughput_modes_bounded(prec, tol):
     g = load_golden("g6_training_3")
     loss, got, _ = _render_bwd_on_reference_samples(g, prec)
