@@ -1,44 +1,54 @@
 #!/usr/bin/env python3
 """bench.py - ray-samples/s of the EMAP render hot path on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--rays 512] [--precision bf16x3|bf16]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode render|train] [--rays 512] [--precision f16x3|...]
 
-One "step" = one ``UDFRendererBlending.render()`` forward (coarse sampling -> 4 occlusion-aware
-up-sampling steps -> UDF MLP value+gradient at 128 samples/ray -> compositing) over one batch of
-synthetic rays, entirely on the GPU (inputs resident in HBM before the timed region).
-Workload at N=1: the north-star batch, 512 rays x (64 coarse + 64 fine in 4 steps) = 128 samples,
-UDF MLP d=8 w=256 multires=10 (SURVEY.md par. 8d).  For N>1 every rank renders its own 512-ray shard of
-one global batch (weak scaling); the forward path has no collective.
+--mode render (default, the headline): one "step" = one ``UDFRendererBlending.render()`` forward (coarse sampling -> 4
+    occlusion-aware up-sampling steps -> UDF MLP value+gradient at 128 samples/ray -> compositing) over one batch of synthetic
+    rays, entirely on the GPU (inputs resident in HBM before the timed region).
+--mode train: one "step" = one optimizer step of ``emap_amd.parallel.Trainer``: that forward, the HIP backward
+    (emap_render_bwd), the gradient all-reduce over RCCL when N > 1, and Adam.
 
-Prints ONE JSON line on rank 0 (see the driver contract in the task statement), including
-  roofline     : the dominant kernel (final value+grad MLP pass) vs the dense bf16 MFMA peak
-  cpu_baseline : the oracle (CPU restatement of the reference) timed on this box's host cores
+Workload at N=1: the north-star batch, 512 rays x (64 coarse + 64 fine in 4 steps) = 128 samples, UDF MLP d=8 w=256
+multires=10 (SURVEY.md par. 8d).  For N>1 every rank takes its own ``--rays`` shard of one global batch generated from a
+shared seed (weak scaling; ``--global-rays R`` fixes the GLOBAL batch instead: strong scaling, e.g. 4096 for BASELINE config
+C4).  ``python bench.py --gpus N`` without a launcher re-executes itself under ``torch.distributed.run`` with N ranks; under a
+launcher it insists that WORLD_SIZE == N.  The forward path has no collective.
+
+Timing: W untimed warm-up steps, then exactly K steps bracketed by barrier + torch.cuda.synchronize() on both sides (max
+over ranks) -> ``value``; each step is additionally bracketed by HIP events (``ms_per_step_median``).  The roofline entry
+comes from a SEPARATE short loop in which the library records HIP events around the dominant kernel on its launch stream.
+
+Prints ONE JSON line on rank 0, including
+  roofline     : the dominant kernel vs the dense fp16/bf16 MFMA peak
+  parity       : measured in this run - the HIP kernels vs the committed reference goldens (tests/golden)
+  cpu_baseline : the oracle (CPU restatement of the reference, pinned by the goldens) timed on this box's host cores
 """
 import argparse
+import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
+import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 F_POINT = 918016          # FLOP per MLP point-forward, d8 w256 (SURVEY par. 7.0 / 8d)
-# measured max error vs the reference goldens (tests/test_gpu_parity.py asserts these bounds): (udf, grad_x udf),
-# relative to the tensor's max magnitude
-MODE_INFO = {
-    "f16x3": {"dtype": "f16x3 (split-fp16 MFMA, 3 passes, fp32 accumulate)", "passes": 3, "udf_err": 8e-7, "grad_err": 2e-5,
-              "meets_1e-4": True},
-    "bf16x3": {"dtype": "bf16x3 (split-bf16 MFMA, 3 passes, fp32 accumulate)", "passes": 3, "udf_err": 7e-6, "grad_err": 3e-5,
-               "meets_1e-4": False},
-    "f16": {"dtype": "f16 (single-pass fp16 MFMA, fp32 accumulate)", "passes": 1, "udf_err": 6e-4, "grad_err": 1.6e-3,
-            "meets_1e-4": False},
-    "bf16": {"dtype": "bf16 (single-pass bf16 MFMA, fp32 accumulate)", "passes": 1, "udf_err": 5e-3, "grad_err": 1.5e-2,
-             "meets_1e-4": False},
+A_FWD = 2639296           # algorithmic FLOP per ray-sample of a forward render (64+64/4)   (SURVEY par. 8d)
+A_TRAIN = 6311360         # ... of a training step
+MODE_DTYPE = {
+    "f16x3": "f16x3 (split-fp16 MFMA, 3 passes, fp32 accumulate)",
+    "bf16x3": "bf16x3 (split-bf16 MFMA, 3 passes, fp32 accumulate)",
+    "f16": "f16 (single-pass fp16 MFMA, fp32 accumulate)",
+    "bf16": "bf16 (single-pass bf16 MFMA, fp32 accumulate)",
 }
-MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak, MI355X_MICROARCH.md
+MFMA_PEAK_TFLOPS = 2500.0  # dense f16/bf16 MFMA peak, MI355X_MICROARCH.md
 
 
 def parse():
@@ -46,14 +56,27 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--rays", type=int, default=512, help="rays per GPU")
-    ap.add_argument("--precision", default=os.environ.get("EMAP_BENCH_PRECISION", "f16x3"),
-                    choices=["f16x3", "bf16x3", "f16", "bf16"],
+    ap.add_argument("--mode", default="render", choices=["render", "train"])
+    ap.add_argument("--rays", type=int, default=512, help="rays per GPU (weak scaling)")
+    ap.add_argument("--global-rays", type=int, default=0, help="rays of the GLOBAL batch, split over the ranks (strong scaling)")
+    ap.add_argument("--precision", default=os.environ.get("EMAP_BENCH_PRECISION", "f16x3"), choices=list(MODE_DTYPE),
                     help="arithmetic of the MLP GEMMs for `value`; f16x3 is the mode that meets the 1e-4 parity gate")
+    ap.add_argument("--eikonal-sync", default="exact", choices=["exact", "local"], help="train mode, N > 1 (emap_amd/parallel.py)")
     ap.add_argument("--no-other-modes", action="store_true", help="skip the short runs of the other precision modes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-rays", type=int, default=256)
+    ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--cpu-rays", type=int, default=512)
     return ap.parse_args()
+
+
+def relaunch_under_launcher(n):
+    """`python bench.py --gpus N` without a launcher: spawn N ranks (one per GPU) and pass their output through."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def build_renderer(dev, precision):
@@ -71,37 +94,104 @@ def build_renderer(dev, precision):
     return r, state, kw
 
 
-def cpu_baseline(state, kw, n_rays, threads):
-    """The oracle (CPU restatement pinned to the reference by tests/golden) on the same synthetic workload."""
+def measure_parity(dev, precision):
+    """HIP kernels vs the committed reference goldens, in this run: MLP value / grad_x (g2), rendered edge (g5) and the
+    training gradients on the reference's own samples are covered by tests/; here the two cheapest are re-measured."""
+    import emap_amd
+    gd = os.path.join(ROOT, "tests", "golden")
+    g2 = np.load(os.path.join(gd, "g2_mlp.npz"))
+    name = "d8w256L10"
+    kw = dict(d_in=3, d_out=1, d_hidden=256, n_layers=8, skip_in=(4,), multires=10, bias=0.5)
+    from emap_amd import synthetic
+    net = emap_amd.UDFNetwork(scale=1.0, precision=precision, **kw)
+    net.load_state_dict(synthetic.make_udf_state(seed=42, pert=0.02, **kw))
+    net = net.to(dev)
+    x = torch.from_numpy(g2["x"]).to(dev)
+    rel = lambda a, b: float((a.double().cpu().reshape(-1) - b.double().reshape(-1)).abs().max() / b.double().abs().max())
+    with torch.no_grad():
+        u, g = net.hip_udf(x, with_grad=True)
+        # the reverse-sweep kernel serves launches >= 10240 points: evaluate the same points inside a large launch too
+        xb = torch.cat([x, torch.rand(20000, 3, device=dev) * 2 - 1])
+        ub, gb = net.hip_udf(xb, with_grad=True)
+    ref_u, ref_g = torch.from_numpy(g2[f"{name}.out"])[:, :1], torch.from_numpy(g2[f"{name}.grad"]).reshape(-1, 3)
+    out = {"mode": precision, "udf_rel_err": rel(u, ref_u), "grad_rel_err": max(rel(g, ref_g), rel(gb[:x.shape[0]], ref_g)),
+           "reference": "tests/golden/g2_mlp.npz, g5_render_c64_64_4.npz (recorded from the imported reference)"}
+    g5 = np.load(os.path.join(gd, "g5_render_c64_64_4.npz"))
+    devn = emap_amd.SingleVarianceNetwork(0.3).to(dev)
+    bet = emap_amd.BetaNetwork(0.5, 0.3, 0.3, 5e-5, True, True, False).to(dev)
+    r = emap_amd.UDFRendererBlending(None, net, devn, bet, 64, 64, 0, 4, 1.0, device=dev)
+    a = [torch.from_numpy(g5[k]).to(dev) for k in ("rays_o", "rays_d", "near", "far", "depth_scale")]
+    with torch.no_grad():
+        o = r.render(*a, cos_anneal_ratio=1.0, perturb_overwrite=0, flip_saturation=0.9)
+    out["edge_rel_err"] = rel(o["edge"], torch.from_numpy(g5["out.edge"]))
+    out["meets_1e-4"] = bool(out["udf_rel_err"] <= 1e-4 and out["grad_rel_err"] <= 1e-4 and out["edge_rel_err"] <= 1e-4)
+    return out
+
+
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(state, kw, n_rays, mode):
+    """The oracle (CPU restatement pinned to the reference by tests/golden) on the same synthetic workload, on all host cores
+    (BASELINE.md par. 3) plus a single-thread figure on a smaller sample; bounded to about 30 s."""
     from oracle import emap_oracle as O
     from emap_amd import synthetic
-    torch.set_num_threads(threads)
+    threads = os.cpu_count() or 1
     cfg = O.UDFConfig(d_in=3, d_out=1, d_hidden=kw["d_hidden"], n_layers=kw["n_layers"], skip_in=(4,), multires=kw["multires"])
     rcfg = O.RenderConfig(n_samples=64, n_importance=64, up_sample_steps=4)
-    ro, rd, near, far, ds = synthetic.make_rays(n_rays, seed=1)
-    tr = synthetic.make_t_rand(n_rays)
     var, bp, gp = torch.tensor([0.3]), torch.tensor([0.5]), torch.tensor([0.3])
-    run = lambda: O.render(state, cfg, rcfg, ro, rd, near, far, ds, var, bp, gp, cos_anneal_ratio=1.0, t_rand=tr,
-                           flip_saturation=0.9)
-    t0 = time.perf_counter(); run(); first = time.perf_counter() - t0  # warm-up, also sizes the sample
-    ts = []
-    t_end = time.time() + 12.0
-    while len(ts) < (1 if first > 8.0 else 3) or (time.time() < t_end and len(ts) < 20):
-        t0 = time.perf_counter(); run(); ts.append(time.perf_counter() - t0)
-    ts.sort()
-    med = ts[len(ts) // 2]
-    return {"value": n_rays * 128 / med, "unit": "ray-samples/s", "cores": threads, "kind": "port",
-            "sample": f"{n_rays} rays x 128 samples, forward render(), median of {len(ts)} runs ({med*1e3:.0f} ms each), "
-                      f"oracle/emap_oracle.py on torch CPU fp32"}
+
+    def make(n):
+        ro, rd, near, far, ds = synthetic.make_rays(n, seed=1)
+        tr = synthetic.make_t_rand(n)
+        te = synthetic.make_true_edge(n, seed=11)
+        if mode == "train":
+            return lambda: O.loss_and_param_grads(state, cfg, rcfg, ro, rd, near, far, ds, te, var, bp, gp, 1.0, 0.9, t_rand=tr,
+                                                  edge_weight=1.0, igr_weight=0.1, igr_ns_weight=0.0)
+        return lambda: O.render(state, cfg, rcfg, ro, rd, near, far, ds, var, bp, gp, cos_anneal_ratio=1.0, t_rand=tr, flip_saturation=0.9)
+
+    def timed(fn, budget_s, max_runs):
+        t0 = time.perf_counter(); fn(); first = time.perf_counter() - t0     # warm-up, also sizes the sample
+        ts, t_end = [], time.time() + budget_s
+        while len(ts) < (1 if first > budget_s / 2 else 3) or (time.time() < t_end and len(ts) < max_runs):
+            t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
+        ts.sort()
+        return ts[len(ts) // 2], len(ts)
+
+    torch.set_num_threads(threads)
+    med, n = timed(make(n_rays), 14.0, 9)
+    n1 = max(16, n_rays // 16)
+    torch.set_num_threads(1)
+    med1, k1 = timed(make(n1), 8.0, 5)
+    torch.set_num_threads(threads)
+    what = "forward render()" if mode == "render" else "forward + loss.backward() (autograd double backward)"
+    return {"value": n_rays * 128 / med, "unit": "ray-samples/s", "cores": threads, "kind": "port", "cpu_model": cpu_model(),
+            "single_thread_value": n1 * 128 / med1,
+            "sample": f"{n_rays} rays x 128 samples, {what}, median of {n} runs ({med * 1e3:.0f} ms each) on {threads} threads; "
+                      f"single thread: {n1} rays, median of {k1} runs ({med1 * 1e3:.0f} ms each); oracle/emap_oracle.py on torch CPU fp32"}
 
 
 def main():
     a = parse()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    launched = "WORLD_SIZE" in os.environ
+    if a.gpus > 1 and not launched:
+        if torch.cuda.device_count() < a.gpus:
+            raise SystemExit(f"bench.py --gpus {a.gpus}: only {torch.cuda.device_count()} GPU(s) visible")
+        sys.exit(relaunch_under_launcher(a.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    if world != a.gpus:
+        raise SystemExit(f"bench.py --gpus {a.gpus} was launched with WORLD_SIZE={world}: refusing to report n_gpus != ranks")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -109,118 +199,169 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
-    n_gpus = max(a.gpus, world)
+        assert dist.get_world_size() == a.gpus
 
     from emap_amd import synthetic, _lib
+    rays = a.rays
+    scaling = "weak"
+    if a.global_rays:
+        assert a.global_rays % world == 0
+        rays, scaling = a.global_rays // world, "strong"
     r, state, kw = build_renderer(dev, a.precision)
     S = r.samples_per_ray
     # one global batch from a shared seed, sliced by rank (SURVEY par. 8e)
-    g = [t for t in synthetic.make_rays(a.rays * world, seed=1)]
-    tr = synthetic.make_t_rand(a.rays * world)
-    sl = slice(rank * a.rays, (rank + 1) * a.rays)
+    g = [t for t in synthetic.make_rays(rays * world, seed=1)]
+    tr = synthetic.make_t_rand(rays * world)
+    te = synthetic.make_true_edge(rays * world, seed=11)
+    sl = slice(rank * rays, (rank + 1) * rays)
     ro, rd, near, far, ds = [t[sl].contiguous().to(dev) for t in g]
-    tr = tr[sl].contiguous().to(dev)
+    tr, te = tr[sl].contiguous().to(dev), te[sl].contiguous().to(dev)
 
-    def step():
-        return r.render(ro, rd, near, far, ds, cos_anneal_ratio=1.0, flip_saturation=0.9, t_rand=tr)
+    trainer = None
+    if a.mode == "train":
+        from emap_amd.parallel import Trainer
+        trainer = Trainer(r, lr_geo=1e-4, lr=5e-4, edge_weight=1.0, igr_weight=0.1, igr_ns_weight=0.0, eikonal_sync=a.eikonal_sync)
+        batch = {"rays_o": ro, "rays_d": rd, "near": near, "far": far, "depth_scale": ds, "cos_anneal_ratio": 1.0,
+                 "flip_saturation": 0.9, "t_rand": tr}
+
+        def step():
+            return trainer.step(batch, te, n_rays_global=rays * world)
+    else:
+        def step():
+            with torch.no_grad():
+                return r.render(ro, rd, near, far, ds, cos_anneal_ratio=1.0, flip_saturation=0.9, t_rand=tr)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    L = _lib.lib()
-    with torch.no_grad():
-        for _ in range(a.warmup):
-            out = step()
-        barrier()
-        _lib.check(L.emap_profile_enable(1))
-        t0 = time.perf_counter()
-        for _ in range(a.steps):
-            out = step()
-        barrier()
-        dt = time.perf_counter() - t0
-        _lib.check(L.emap_profile_enable(0))
-    r.check_errors()
-    if dist is not None:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    parity = None
+    if rank == 0 and not a.no_parity:
+        try:
+            parity = measure_parity(dev, a.precision)
+        except Exception as e:   # pragma: no cover
+            parity = {"error": repr(e)}
 
-    import ctypes as C
+    L = _lib.lib()
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    t0 = time.perf_counter()
+    for s_ev, e_ev in evs:
+        s_ev.record()
+        step()
+        e_ev.record()
+    barrier()
+    dt = time.perf_counter() - t0
+    r.check_errors()
+    per_step = sorted(s_ev.elapsed_time(e_ev) for s_ev, e_ev in evs)
+    med_ms = per_step[len(per_step) // 2]
+    if dist is not None:
+        tt = torch.tensor([dt, med_ms], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt, med_ms = float(tt[0]), float(tt[1])
+
+    # roofline: a second, short loop with the library's HIP events around the dominant kernel (not in the headline loop)
+    which = 1 if a.mode == "train" else 0
+    _lib.check(L.emap_profile_enable(1))
+    for _ in range(min(a.steps, 20)):
+        step()
+    torch.cuda.synchronize()
+    _lib.check(L.emap_profile_enable(0))
     kms, kn = C.c_float(), C.c_int()
-    _lib.check(L.emap_profile_read(C.byref(kms), C.byref(kn)))
+    _lib.check(L.emap_profile_read_kernel(which, C.byref(kms), C.byref(kn)))
     k_avg_s = (kms.value / max(kn.value, 1)) * 1e-3
+    loss_now = trainer.last_stats.tolist() if trainer is not None else None
 
     if rank == 0:
         ms_per_step = dt / a.steps * 1e3
-        value = a.rays * world * S / (dt / a.steps)
-        # dominant kernel: the value+grad MLP launch over rays*S points; algorithmic work = value +
-        # reverse-mode input gradient = 2F per point (SURVEY par. 8d)
-        flops_launch = a.rays * S * 2 * F_POINT
-        # udf_mlp.hip:mlp_variant: reverse-sweep kernel for grad launches of >= 10240 (f16x3) / 16384 (single-pass) points, not bf16x3
-        dominant_kernel = (f"udf_mlp_rev_kernel<256,{a.precision}>" if (a.rays * S >= (10240 if a.precision == "f16x3" else 16384) and a.precision != "bf16x3")
-                           else f"udf_mlp_fs2_kernel<256,{a.precision},4,grad>")
+        value = rays * world * S / (dt / a.steps)
+        if a.mode == "train":
+            # dominant kernel: the per-point sweep of the MLP double backward (value + one tangent column forward, two adjoint
+            # columns backward) = 2F + 2F of the 6F the backward has to do per point; the weight-gradient GEMMs are a second kernel
+            flops_launch = rays * S * 4 * F_POINT
+            dominant = f"udf_mlp_vjp_kernel<256,{a.precision},8> (forward recompute + reverse sweep of the double backward)"
+            alg = A_TRAIN
+            metric = "ray-samples/sec (training step: render fwd + HIP bwd + all-reduce + Adam)"
+            workload = "optimizer step (emap_amd.parallel.Trainer)"
+        else:
+            # dominant kernel: the value+grad MLP launch over rays*S points; algorithmic work = value + reverse-mode input
+            # gradient = 2F per point (SURVEY par. 8d)
+            flops_launch = rays * S * 2 * F_POINT
+            rev = rays * S >= (10240 if a.precision == "f16x3" else 16384) and a.precision != "bf16x3"
+            dominant = (f"udf_mlp_rev_kernel<256,{a.precision}>" if rev else f"udf_mlp_fs2_kernel<256,{a.precision},4,grad>") + " (final value+grad pass)"
+            alg = A_FWD
+            metric = "ray-samples/sec (UDF MLP + composite)"
+            workload = "forward render()"
         ach = flops_launch / k_avg_s / 1e12 if k_avg_s > 0 else 0.0
         line = {
-            "metric": "ray-samples/sec (UDF MLP + composite)", "value": value, "unit": "ray-samples/s",
-            "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": MODE_INFO[a.precision]["dtype"],
-            "data": "synthetic",
-            "config": {"workload": f"{a.rays} rays/GPU x {S} samples (64 coarse + 64 fine in 4 up-sampling steps), "
-                                   f"UDF MLP d=8 w=256 multires=10, forward render()",
-                       "rays_per_gpu": a.rays, "samples_per_ray": S, "precision": a.precision,
-                       "parallelism": f"dp{world} over rays, no collective in forward"},
-            "roofline": {"bound": "mfma", "kernel": dominant_kernel + " (final value+grad pass)",
-                         "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
-                         "avg_launch_us": k_avg_s * 1e6, "launches": kn.value,
+            "metric": metric, "value": value, "unit": "ray-samples/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step, "ms_per_step_median": med_ms,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+            "dtype": MODE_DTYPE[a.precision], "data": "synthetic",
+            "config": {"workload": f"{rays} rays/GPU x {S} samples (64 coarse + 64 fine in 4 up-sampling steps), "
+                                   f"UDF MLP d=8 w=256 multires=10, {workload}",
+                       "rays_per_gpu": rays, "rays_global": rays * world, "samples_per_ray": S, "precision": a.precision,
+                       "mode": a.mode,
+                       "parallelism": f"dp{world} over rays" + (", no collective in forward" if a.mode == "render" else
+                                                               f", {trainer.collectives_per_step} collective(s) per step "
+                                                               f"(eikonal_sync={a.eikonal_sync}: "
+                                                               + ("20 B stats + " if a.eikonal_sync == "exact" and world > 1 else "")
+                                                               + f"one flat {4 * (trainer.flat.numel + trainer.N_STATS)} B gradient all-reduce)"),
+                       "ranks": world, "devices": list(range(world))},
+            "roofline": {"bound": "mfma", "kernel": dominant, "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach / MFMA_PEAK_TFLOPS, "avg_launch_us": k_avg_s * 1e6, "launches": kn.value,
                          "algorithmic_flops_per_launch": flops_launch, "traffic": None},
-            "whole_render_algorithmic_tflops": value * 2639296 / 1e12,
-            "parity": {"mode": a.precision, "udf_rel_err": MODE_INFO[a.precision]["udf_err"],
-                       "grad_rel_err": MODE_INFO[a.precision]["grad_err"], "meets_1e-4": MODE_INFO[a.precision]["meets_1e-4"],
-                       "checked_by": "tests/test_gpu_parity.py vs tests/golden (reference outputs)"},
+            "whole_step_algorithmic_tflops": value * alg / 1e12,
+            "whole_step_frac_of_mfma_peak": value * alg / 1e12 / MFMA_PEAK_TFLOPS / world,
         }
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if loss_now is not None:
+            line["loss_after_run"] = loss_now
+        if parity is not None:
+            line["parity"] = parity
+        tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
         if os.path.exists(tpath):
             try:
-                tj = json.load(open(tpath))
-                ent = tj.get(a.precision)
+                ent = json.load(open(tpath)).get(f"{a.mode}:{a.precision}")
                 if ent:
                     line["roofline"]["traffic"] = ent["hbm_bytes_per_launch"]
-                    line["roofline"]["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel)"
+                    line["roofline"]["traffic_source"] = "profiles/r02_traffic.json (rocprofv3 --pmc passes of this kernel, MI355X_MICROARCH.md corrections)"
             except Exception:
                 pass
-        if not a.no_other_modes and world == 1:
+        if not a.no_other_modes and world == 1 and a.mode == "render":
             other = {}
-            for mode in MODE_INFO:
+            for mode in MODE_DTYPE:
                 if mode == a.precision:
                     continue
                 try:
                     r.precision = mode
-                    with torch.no_grad():
-                        for _ in range(5):
-                            step()
-                        torch.cuda.synchronize()
-                        t1 = time.perf_counter()
-                        n_o = max(20, a.steps // 4)
-                        for _ in range(n_o):
-                            step()
-                        torch.cuda.synchronize()
-                        dto = (time.perf_counter() - t1) / n_o
-                    other[mode] = {"value": a.rays * S / dto, "ms_per_step": dto * 1e3, "udf_rel_err": MODE_INFO[mode]["udf_err"],
-                                   "grad_rel_err": MODE_INFO[mode]["grad_err"], "meets_1e-4": MODE_INFO[mode]["meets_1e-4"]}
+                    for _ in range(5):
+                        step()
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    n_o = max(20, a.steps // 4)
+                    for _ in range(n_o):
+                        step()
+                    torch.cuda.synchronize()
+                    dto = (time.perf_counter() - t1) / n_o
+                    pm = measure_parity(dev, mode) if not a.no_parity else {}
+                    other[mode] = {"value": rays * S / dto, "ms_per_step": dto * 1e3, "udf_rel_err": pm.get("udf_rel_err"),
+                                   "grad_rel_err": pm.get("grad_rel_err"), "edge_rel_err": pm.get("edge_rel_err"),
+                                   "meets_1e-4": pm.get("meets_1e-4")}
                 except Exception as e:
                     other[mode] = {"error": repr(e)}
             r.precision = a.precision
             line["other_precision_modes"] = other
         if not a.no_cpu_baseline and world == 1:
             try:
-                line["cpu_baseline"] = cpu_baseline(state, kw, a.cpu_rays, min(32, os.cpu_count() or 1))
+                line["cpu_baseline"] = cpu_baseline(state, kw, a.cpu_rays, a.mode)
             except Exception as e:  # the baseline must never take the GPU line down
                 line["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(line), flush=True)
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -94,6 +94,7 @@ SYMBOLS = {
                                   C.POINTER(CompositeGrads), C.POINTER(ParamGrads), _P, C.c_size_t, _P, _P]),
     "emap_profile_enable": (C.c_int, [C.c_int]),
     "emap_profile_read": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    "emap_profile_read_kernel": (C.c_int, [C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "emap_linspace_host": (None, [C.c_float, C.c_float, C.c_int, C.POINTER(C.c_float)]),
 }
 

@@ -28,6 +28,21 @@ int check_launch(const char* what) {
     return EMAP_OK;
 }
 
+// ---- optional per-launch timing of the dominant kernel (the final value+grad MLP pass) ----------
+// bench.py enables it for the timed region; hipEvents are recorded on the launch stream right
+// before/after that kernel, and read back after the region's final synchronisation.
+constexpr int PROF_MAX = 1024;
+constexpr int PROF_KERNELS = 3;   // 0: final value+grad pass of render_fwd, 1: udf_mlp_vjp sweep, 2: wgrad GEMMs (render_bwd / udf_vjp)
+static bool g_prof_on = false;
+static int g_prof_n[PROF_KERNELS] = {0, 0, 0};
+static hipEvent_t g_prof_ev[PROF_KERNELS][PROF_MAX][2];
+static bool g_prof_init = false;
+struct ProfScope {   // records a HIP event pair around one launch on its stream while profiling is enabled
+    int k; hipStream_t st; bool on;
+    ProfScope(int k_, hipStream_t st_) : k(k_), st(st_), on(g_prof_on && g_prof_n[k_] < PROF_MAX) { if (on) (void)hipEventRecord(g_prof_ev[k][g_prof_n[k]][0], st); }
+    ~ProfScope() { if (on) { (void)hipEventRecord(g_prof_ev[k][g_prof_n[k]][1], st); ++g_prof_n[k]; } }
+};
+
 int launch_sample_pdf(const float*, const float*, int, int, int, float*, int64_t*, int32_t*, hipStream_t);
 int launch_upsample(const float*, const float*, const float*, const float*, int, int, int, const float*, float, float,
                     float, float*, int64_t*, int32_t*, hipStream_t);
@@ -46,14 +61,14 @@ int launch_composite_bwd(const float*, const float*, const float*, const float*,
 // ---- training backward (udf_mlp_vjp.inc, wgrad.hip) ----
 #define EMAP_VJP_DECL(m) \
     int launch_vjp_sweep_##m(const NetLayout&, const void*, const PointSource&, int64_t, int, int, const float*, const float*, \
-                             const VjpLayout&, char*, char*, char*, int, const uint32_t*, hipStream_t, int32_t*);
+                             const VjpLayout&, char*, char*, char*, int, const uint32_t*, float*, hipStream_t, int32_t*);
 EMAP_VJP_DECL(bf16) EMAP_VJP_DECL(bf16x3) EMAP_VJP_DECL(f16) EMAP_VJP_DECL(f16x3)
 #undef EMAP_VJP_DECL
 size_t plan_wgrad(const NetLayout&, const VjpLayout&, int, WgradJob*, int*, int*, int*, int*);
 int launch_absmax(const float*, const float*, int64_t, uint32_t*, hipStream_t);
 int launch_wgrad(const NetLayout&, const VjpLayout&, const WgradJob*, int, int, const char*, const char*, float*, int, int,
                  hipStream_t);
-int launch_wgrad_reduce(const NetLayout&, const WgradJob*, int, const int*, const int*, const float*, const uint32_t*,
+int launch_wgrad_reduce(const NetLayout&, const WgradJob*, int, const int*, const int*, const float*, const uint32_t*, const float*, int,
                         const float* const*, const float* const*, float* const*, float* const*, float* const*, int, int, float,
                         hipStream_t);
 
@@ -72,7 +87,7 @@ struct VjpPlan {
     VjpLayout V;
     WgradJob jobs[WGRAD_MAX_JOBS];
     int n_jobs, job_h[EMAP_MAX_LIN], job_pe[EMAP_MAX_LIN], wgrad_wg, sweep_grid, chunk_tiles;
-    size_t off_absmax, off_slab, off_partial, off_a, off_z, total;
+    size_t off_absmax, off_slab, off_partial, off_ldot, off_a, off_z, total;
 };
 
 static VjpPlan plan_vjp(const NetLayout& L, int64_t P) {
@@ -87,6 +102,7 @@ static VjpPlan plan_vjp(const NetLayout& L, int64_t P) {
     pl.off_absmax = off; off += 256;
     pl.off_slab = off; off += (size_t)pl.sweep_grid * pl.V.s_slab_kb * 1024;
     pl.off_partial = off; off += ((pfl * 4 + 255) & ~(size_t)255);
+    pl.off_ldot = off; off += (((size_t)std::max<int64_t>(tiles, 1) * 4 + 255) & ~(size_t)255);
     pl.off_a = off; off += (size_t)pl.chunk_tiles * pl.V.a_tile_kb * 1024;
     pl.off_z = off; off += (size_t)pl.chunk_tiles * pl.V.z_tile_kb * 1024;
     pl.total = off;
@@ -98,23 +114,28 @@ static int run_vjp(const NetLayout& L, const void* packed, int prec, const Point
                    const float* d_grad, const EmapParamGrads* out, const VjpPlan& pl, char* ws, int32_t* err, hipStream_t st) {
     uint32_t* absmax = reinterpret_cast<uint32_t*>(ws + pl.off_absmax);
     float* partial = reinterpret_cast<float*>(ws + pl.off_partial);
+    float* ldot = reinterpret_cast<float*>(ws + pl.off_ldot);
     const int64_t tiles = (P + VJP_PT - 1) / VJP_PT;
     int chunk = 0;
     for (int64_t t0 = 0; t0 < tiles || chunk == 0; t0 += pl.chunk_tiles, ++chunk) {
         const int nt = (int)std::min<int64_t>(pl.chunk_tiles, std::max<int64_t>(tiles - t0, 0));
         int rc = EMAP_OK;
+        {
+        ProfScope ps(1, st);
         switch (prec) {
-            case EMAP_PREC_BF16: rc = launch_vjp_sweep_bf16(L, packed, src, P, (int)t0, nt, d_udf, d_grad, pl.V, ws + pl.off_a, ws + pl.off_z, ws + pl.off_slab, pl.sweep_grid, absmax, st, err); break;
-            case EMAP_PREC_BF16X3: rc = launch_vjp_sweep_bf16x3(L, packed, src, P, (int)t0, nt, d_udf, d_grad, pl.V, ws + pl.off_a, ws + pl.off_z, ws + pl.off_slab, pl.sweep_grid, absmax, st, err); break;
-            case EMAP_PREC_F16: rc = launch_vjp_sweep_f16(L, packed, src, P, (int)t0, nt, d_udf, d_grad, pl.V, ws + pl.off_a, ws + pl.off_z, ws + pl.off_slab, pl.sweep_grid, absmax, st, err); break;
-            default: rc = launch_vjp_sweep_f16x3(L, packed, src, P, (int)t0, nt, d_udf, d_grad, pl.V, ws + pl.off_a, ws + pl.off_z, ws + pl.off_slab, pl.sweep_grid, absmax, st, err); break;
+            case EMAP_PREC_BF16: rc = launch_vjp_sweep_bf16(L, packed, src, P, (int)t0, nt, d_udf, d_grad, pl.V, ws + pl.off_a, ws + pl.off_z, ws + pl.off_slab, pl.sweep_grid, absmax, ldot, st, err); break;
+            case EMAP_PREC_BF16X3: rc = launch_vjp_sweep_bf16x3(L, packed, src, P, (int)t0, nt, d_udf, d_grad, pl.V, ws + pl.off_a, ws + pl.off_z, ws + pl.off_slab, pl.sweep_grid, absmax, ldot, st, err); break;
+            case EMAP_PREC_F16: rc = launch_vjp_sweep_f16(L, packed, src, P, (int)t0, nt, d_udf, d_grad, pl.V, ws + pl.off_a, ws + pl.off_z, ws + pl.off_slab, pl.sweep_grid, absmax, ldot, st, err); break;
+            default: rc = launch_vjp_sweep_f16x3(L, packed, src, P, (int)t0, nt, d_udf, d_grad, pl.V, ws + pl.off_a, ws + pl.off_z, ws + pl.off_slab, pl.sweep_grid, absmax, ldot, st, err); break;
+        }
         }
         if (rc) return rc;
+        ProfScope pw(2, st);
         rc = launch_wgrad(L, pl.V, pl.jobs, pl.n_jobs, pl.wgrad_wg, ws + pl.off_a, ws + pl.off_z, partial, nt, chunk > 0 ? 1 : 0, st);
         if (rc) return rc;
         if (tiles == 0) break;
     }
-    return launch_wgrad_reduce(L, pl.jobs, pl.n_jobs, pl.job_h, pl.job_pe, partial, absmax, out->g_host, out->v_host, out->dg_host,
+    return launch_wgrad_reduce(L, pl.jobs, pl.n_jobs, pl.job_h, pl.job_pe, partial, absmax, ldot, (int)tiles, out->g_host, out->v_host, out->dg_host,
                                out->dv_host, out->db_host, out->weight_norm, out->accumulate, out->grad_scale, st);
 }
 
@@ -131,15 +152,6 @@ static int check_param_grads(const NetLayout& L, const EmapParamGrads* o, const 
 }
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
-
-// ---- optional per-launch timing of the dominant kernel (the final value+grad MLP pass) ----------
-// bench.py enables it for the timed region; hipEvents are recorded on the launch stream right
-// before/after that kernel, and read back after the region's final synchronisation.
-constexpr int PROF_MAX = 4096;
-static bool g_prof_on = false;
-static int g_prof_n = 0;
-static hipEvent_t g_prof_ev[PROF_MAX][2];
-static bool g_prof_init = false;
 
 struct Workspace {
     size_t sample_dist, z_a, z_b, udf_a, udf_b, z_new, udf_new, partials, rev, total;
@@ -355,10 +367,10 @@ int emap_render_fwd(const EmapNetConfig* cfg, const void* packed, int prec, cons
     PointSource fin;
     memset(&fin, 0, sizeof(fin));
     fin.rays_o = rays_o; fin.rays_d = rays_d; fin.z = z_vals; fin.n_per_ray = S; fin.mid = 1; fin.sample_dist = sample_dist;
-    const bool prof = g_prof_on && g_prof_n < PROF_MAX;
-    if (prof) (void)hipEventRecord(g_prof_ev[g_prof_n][0], st);
-    rc = launch_mlp(L, packed, prec, fin, (int64_t)N * S, udf, grad3, st, err_flags, ws + w.rev);
-    if (prof) { (void)hipEventRecord(g_prof_ev[g_prof_n][1], st); ++g_prof_n; }
+    {
+        ProfScope ps(0, st);
+        rc = launch_mlp(L, packed, prec, fin, (int64_t)N * S, udf, grad3, st, err_flags, ws + w.rev);
+    }
     if (rc) return rc;
     return launch_composite(rays_o, rays_d, z_vals, udf, grad3, depth_scale, N, S, sample_dist, p->inv_s, p->beta, p->gamma,
                             p->cos_anneal_ratio, p->has_cos_anneal, p->flip_saturation, p->near_surface, p->sparse_scale,
@@ -475,28 +487,31 @@ int emap_null_direction(const float* grads, int64_t n, int k, float* dir, void* 
 
 int emap_profile_enable(int on) {
     if (on && !g_prof_init) {
-        for (int i = 0; i < PROF_MAX; ++i)
-            for (int k = 0; k < 2; ++k)
-                if (hipEventCreate(&g_prof_ev[i][k]) != hipSuccess) { set_error("hipEventCreate failed"); return EMAP_E_LAUNCH; }
+        for (int k = 0; k < PROF_KERNELS; ++k)
+            for (int i = 0; i < PROF_MAX; ++i)
+                for (int e = 0; e < 2; ++e)
+                    if (hipEventCreate(&g_prof_ev[k][i][e]) != hipSuccess) { set_error("hipEventCreate failed"); return EMAP_E_LAUNCH; }
         g_prof_init = true;
     }
     g_prof_on = on != 0;
-    if (on) g_prof_n = 0;
+    if (on) for (int k = 0; k < PROF_KERNELS; ++k) g_prof_n[k] = 0;
     return EMAP_OK;
 }
 
-int emap_profile_read(float* total_ms_host, int* launches_host) {
-    if (!total_ms_host || !launches_host) { set_error("profile_read: null pointer"); return EMAP_E_INVALID; }
+int emap_profile_read_kernel(int which, float* total_ms_host, int* launches_host) {
+    if (!total_ms_host || !launches_host || which < 0 || which >= PROF_KERNELS) { set_error("profile_read: bad argument"); return EMAP_E_INVALID; }
     float tot = 0.f;
-    for (int i = 0; i < g_prof_n; ++i) {
+    for (int i = 0; i < g_prof_n[which]; ++i) {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, g_prof_ev[i][0], g_prof_ev[i][1]) != hipSuccess) { set_error("hipEventElapsedTime failed (region not synchronised?)"); return EMAP_E_LAUNCH; }
+        if (hipEventElapsedTime(&ms, g_prof_ev[which][i][0], g_prof_ev[which][i][1]) != hipSuccess) { set_error("hipEventElapsedTime failed (region not synchronised?)"); return EMAP_E_LAUNCH; }
         tot += ms;
     }
     *total_ms_host = tot;
-    *launches_host = g_prof_n;
+    *launches_host = g_prof_n[which];
     return EMAP_OK;
 }
+
+int emap_profile_read(float* total_ms_host, int* launches_host) { return emap_profile_read_kernel(0, total_ms_host, launches_host); }
 
 /* host-only helper used by the CPU tests: the u grid of sample_pdf / the coarse z grid */
 void emap_linspace_host(float start, float end, int steps, float* out_host) { linspace_host(start, end, steps, out_host); }

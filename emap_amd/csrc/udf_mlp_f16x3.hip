@@ -13,8 +13,8 @@ int launch_mlp_f16x3(const NetLayout& L, const void* packed, const PointSource& 
 }
 int launch_vjp_sweep_f16x3(const NetLayout& L, const void* packed, const PointSource& src, int64_t P, int tile0, int n_tiles,
                             const float* d_udf, const float* d_grad, const VjpLayout& V, char* stash_a, char* stash_z, char* stash_s,
-                            int grid, const uint32_t* absmax, hipStream_t st, int32_t* err) {
+                            int grid, const uint32_t* absmax, float* ldot, hipStream_t st, int32_t* err) {
     return launch_vjp_sweep_mode<EMAP_PREC_F16X3>(L, packed, src, P, tile0, n_tiles, d_udf, d_grad, V, stash_a, stash_z, stash_s, grid,
-                                                 absmax, st, err);
+                                                 absmax, ldot, st, err);
 }
 }  // namespace emap

@@ -200,6 +200,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgradArgs a) {
 struct ReduceArgs {
     const float* partial;
     const uint32_t* absmax;
+    const float* ldot;          // per-tile exact sums for the last layer's dot(dW, v) (udf_mlp_vjp.inc)
+    int32_t n_tiles;
     float grad_scale;           // extra factor on every gradient (1/world for data-parallel means; 1 otherwise)
     int32_t accumulate;         // 1: add to dg/dv/db instead of overwriting
     int32_t weight_norm;        // 0: dv = dW (g is ignored, dg untouched)
@@ -285,6 +287,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const ReduceArgs a) {
     }
     dot = wave_sum_f(dot);
     nrm = wave_sum_f(nrm);
+    if (last && a.weight_norm && a.g[l][o] != 0.f) {
+        // exact component of dW along W: dot(dW, v) = (||v||/g) sum_tiles ldot  (fixed order: deterministic)
+        float ld = 0.f;
+        for (int t = lane; t < a.n_tiles; t += 64) ld += a.ldot[t];
+        ld = wave_sum_f(ld);
+        dot = ld * inv_k * sqrtf(nrm) / a.g[l][o];
+    }
     float* dvrow = a.dv[l] + (size_t)o * n_in;
     if (a.weight_norm) {
         const float n = sqrtf(nrm), gg = a.g[l][o];
@@ -383,12 +392,12 @@ int launch_wgrad(const NetLayout& L, const VjpLayout& V, const WgradJob* jobs, i
 }
 
 int launch_wgrad_reduce(const NetLayout& L, const WgradJob* jobs, int n_jobs, const int* job_h, const int* job_pe,
-                        const float* partial, const uint32_t* absmax, const float* const* g, const float* const* v,
+                        const float* partial, const uint32_t* absmax, const float* ldot, int n_tiles, const float* const* g, const float* const* v,
                         float* const* dg, float* const* dv, float* const* db, int weight_norm, int accumulate, float grad_scale,
                         hipStream_t st) {
     ReduceArgs a;
     memset(&a, 0, sizeof(a));
-    a.partial = partial; a.absmax = absmax; a.grad_scale = grad_scale; a.accumulate = accumulate; a.weight_norm = weight_norm;
+    a.partial = partial; a.absmax = absmax; a.ldot = ldot; a.n_tiles = n_tiles; a.grad_scale = grad_scale; a.accumulate = accumulate; a.weight_norm = weight_norm;
     a.n_lin = L.n_lin; a.H = L.H; a.d0 = L.d0; a.multires = L.multires; a.skip_l = L.skip_l;
     int rows = 0;
     for (int l = 0; l < L.n_lin; ++l) {

@@ -249,11 +249,14 @@ int emap_render_bwd(const EmapNetConfig* cfg, const void* packed, int prec, cons
 int emap_null_direction(const float* grads, int64_t n, int k, float* dir, void* stream);
 
 /* ---- measurement ----------------------------------------------------------------------------
- * While enabled, emap_render_fwd brackets its dominant kernel (the final value+gradient MLP pass) with
- * hipEvents on the launch stream; emap_profile_read (after the caller synchronised) returns the summed
- * duration and the number of launches.  Used by bench.py for the roofline figure. */
+ * While enabled, emap_render_fwd / emap_render_bwd bracket their dominant kernels with hipEvents on the launch
+ * stream; emap_profile_read[_kernel] (after the caller synchronised) returns the summed duration and the number of
+ * launches.  Used by bench.py for the roofline figure (in a loop separate from the headline timing). */
 int emap_profile_enable(int on);
 int emap_profile_read(float* total_ms_host, int* launches_host);
+/* which: 0 = final value+gradient MLP pass of emap_render_fwd (same as emap_profile_read), 1 = udf_mlp_vjp sweep,
+ * 2 = weight-gradient GEMMs (both inside emap_render_bwd / emap_udf_vjp) */
+int emap_profile_read_kernel(int which, float* total_ms_host, int* launches_host);
 
 /* host-only: torch.linspace(start, end, steps) in fp32, the grid of sample_pdf's u / the coarse z_vals */
 void emap_linspace_host(float start, float end, int steps, float* out_host);

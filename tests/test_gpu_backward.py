@@ -57,14 +57,18 @@ def _hip_vjp(net, x, du, dg):
 
 
 def _cmp(got, ref, tol, what=""):
+    """every tensor: max|got - ref| <= tol * max|ref| + 1e-6 * (largest gradient entry of the whole set).  Returns the worst
+    error relative to the tensor's own max among the tensors that are not below that floor (for the log)."""
     gmax = max(float(v.abs().max()) for v in ref.values())
     worst = 0.0
     for k, r in ref.items():
         r = r.double().reshape(-1)
         e = float((got[k].double().reshape(-1) - r).abs().max())
-        bound = tol * float(r.abs().max()) + 1e-6 * gmax
-        worst = max(worst, e / (float(r.abs().max()) + 1e-30))
-        assert e <= bound, (what, k, e, float(r.abs().max()))
+        m = float(r.abs().max())
+        bound = tol * m + 1e-6 * gmax
+        if m >= 1e-3 * gmax:
+            worst = max(worst, e / m)
+        assert e <= bound, (what, k, e, m)
     return worst
 
 
