@@ -346,6 +346,106 @@ def test_upsample_and_merge_bit_exact_vs_reference():
         z, udf = t(g[f"step{i}.z_out"]).to(DEV), t(g[f"step{i}.udf_out"]).to(DEV)
 
 
+def _well_conditioned(z, weights, inds, m):
+    """samples whose inverse-CDF lerp is well conditioned: the pdf mass of their interval is >= 1e-3 (sample_pdf :92-96 divides
+    by it; in empty intervals the reference's own result depends on the last ulp of its cumsum)"""
+    w = weights + 1e-5
+    pdf = w / w.sum(-1, keepdim=True)
+    below = (inds - 1).clamp(min=0)
+    above = inds.clamp(max=z.shape[1] - 1)
+    mass = torch.where(above > below, torch.gather(pdf, 1, below.clamp(max=pdf.shape[1] - 1)), torch.zeros_like(z[:, :m]))
+    return mass >= 1e-3
+
+
+@pytest.mark.parametrize("case", ["c64_64_4", "c64_50_5", "c32_32_4_small"])
+def test_upsampling_steps_and_chain_vs_reference(case):
+    """Every one of the K up-sampling steps through the HIP kernels, for the full-size golden renders (G4 pins two steps of a
+    small case bit for bit):
+      (a) each step on the REFERENCE's inputs of that step (z, udf from the oracle trace, which is bit-pinned to the goldens'
+          z_after_step*): searchsorted indices equal, new samples within 2e-6 wherever the inverse CDF is well conditioned,
+          merge permutation and merged z bit-exact;
+      (b) the steps CHAINED (each fed with the previous HIP output): fraction of rays whose final z_vals equal the golden's.
+    The weights feeding sample_pdf go through exp / sigmoid, whose last ulp differs between libm implementations, so
+    ill-conditioned samples (empty intervals) are reported, not asserted."""
+    g = load_golden("g5_render_" + case)
+    ns, ni, steps = [int(v) for v in g["cfg"]]
+    kw, state = net_state(G5[case])
+    cfg = O.UDFConfig(d_hidden=kw["d_hidden"], n_layers=kw["n_layers"], multires=kw["multires"])
+    ro_c, rd_c, near, far = t(g["rays_o"]), t(g["rays_d"]), t(g["near"]), t(g["far"])
+    N, m = ro_c.shape[0], ni // steps
+    z0, sd = O.coarse_z_vals(near, far, ns, N)
+    trace = []
+    O.importance_sample(state, cfg, ro_c, rd_c, z0, sd, ns, ni, steps, trace=trace)
+    # On the machine that recorded the goldens the oracle reproduces z_after_step* bit for bit (tests/test_oracle_vs_golden.py,
+    # CPU suite); on another CPU torch's vectorised exp / sigmoid differ in the last ulp and a few empty-interval samples
+    # move there as well - which is why (a) compares with the oracle evaluated HERE, on identical inputs.
+    host_equal = min(float((trace[i + 1]["z_vals"] == t(g[f"z_after_step{i}"])).all(dim=1).float().mean()) for i in range(steps))
+    L = _lib.lib()
+    ro, rd = ro_c.to(DEV), rd_c.to(DEV)
+    sdt = torch.tensor([sd], device=DEV)
+
+    def hip_step(z, udf, i):
+        n = z.shape[1]
+        inv_s, beta = 64.0 * 2 ** i, 64.0 * 2 ** (i + 1)
+        gamma = float(np.clip(20 * 2 ** (steps - i), 20, 320))
+        zn = torch.empty(N, m, device=DEV)
+        inds = torch.empty(N, m, device=DEV, dtype=torch.int64)
+        _lib.check(L.emap_upsample_step(_lib.ptr(ro), _lib.ptr(rd), _lib.ptr(z), _lib.ptr(udf), N, n, m, _lib.ptr(sdt), inv_s, beta,
+                                        gamma, _lib.ptr(zn), _lib.ptr(inds), None, _lib.stream_ptr()))
+        return zn, inds, (inv_s, beta, gamma)
+
+    def hip_merge(z, zn, udf, un):
+        n = z.shape[1]
+        zo = torch.empty(N, n + m, device=DEV)
+        uo = torch.empty(N, n + m, device=DEV) if un is not None else None
+        perm = torch.empty(N, n + m, device=DEV, dtype=torch.int64)
+        _lib.check(L.emap_merge_sorted(_lib.ptr(z), _lib.ptr(zn), _lib.ptr(udf) if un is not None else None, _lib.ptr(un), N, n, m,
+                                       _lib.ptr(zo), _lib.ptr(uo), _lib.ptr(perm), _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        return zo, uo, perm
+
+    # (a) step by step on reference inputs
+    bad_frac, ind_frac, good_bad = 0.0, 0.0, 0.0
+    for i in range(steps):
+        zr, ur = trace[i]["z_vals"], trace[i]["udf"]
+        zn, inds, (inv_s, beta, gamma) = hip_step(zr.to(DEV).contiguous(), ur.to(DEV).contiguous(), i)
+        ref = O.up_sample_unbias(ro_c, rd_c, zr, ur, sd, m, inv_s, beta, gamma, return_all=True)
+        assert torch.equal(ref["z_samples"], trace[i + 1]["new_z_vals"])
+        same_ind = inds.cpu() == ref["inds"]
+        good = _well_conditioned(zr, ref["weights"], ref["inds"], m) & same_ind
+        dz = (zn.cpu() - ref["z_samples"]).abs()
+        # (a discontinuous decision inside the weights - true_cos < 0.05, |p| < 1 - can also flip on an ulp: counted, not excused)
+        good_bad = max(good_bad, float((dz[good] > 2e-6).float().mean()))
+        ind_frac = max(ind_frac, 1.0 - float(same_ind.float().mean()))
+        bad_frac = max(bad_frac, float((dz > 2e-6).float().mean()))
+        # merge on the reference's new samples: integer bookkeeping, bit-exact
+        last = i + 1 == steps
+        pts = (ro_c[:, None, :] + rd_c[:, None, :] * ref["z_samples"][..., None]).reshape(-1, 3)
+        un = None if last else O.udf_value(state, cfg, pts).reshape(N, m).to(DEV).contiguous()
+        zo, uo, perm = hip_merge(zr.to(DEV).contiguous(), ref["z_samples"].to(DEV).contiguous(), ur.to(DEV).contiguous(), un)
+        assert torch.equal(perm.cpu(), O.merge_sorted(zr, ref["z_samples"])[1]), i
+        assert torch.equal(zo.cpu(), trace[i + 1]["z_vals"]), i
+        if not last:
+            assert torch.equal(uo.cpu(), trace[i + 1]["udf"]), i
+    # (b) chained
+    z, udf = trace[0]["z_vals"].to(DEV).contiguous(), trace[0]["udf"].to(DEV).contiguous()
+    for i in range(steps):
+        last = i + 1 == steps
+        zn, _, _ = hip_step(z, udf, i)
+        un = None
+        if not last:
+            pts = (ro_c[:, None, :] + rd_c[:, None, :] * zn.cpu()[..., None]).reshape(-1, 3)
+            un = O.udf_value(state, cfg, pts).reshape(N, m).to(DEV).contiguous()
+        z, uo, _ = hip_merge(z, zn, udf, un)
+        udf = uo if uo is not None else udf
+    ok_rays = float(((z.cpu() - t(g[f"z_after_step{steps - 1}"])).abs().max(dim=1).values <= 2e-6).float().mean())
+    print(f"up-sampling {case}: per step on reference inputs: index mismatches {ind_frac:.4f}, samples off by > 2e-6 {bad_frac:.4f} "
+          f"(of the well-conditioned ones {good_bad:.4f}); chained: rays with every final z within 2e-6 of the golden {ok_rays:.3f} "
+          f"(this host's CPU oracle vs the golden, bit-equal rays: {host_equal:.3f})")
+    b = CHAIN_BOUND[case]
+    assert ind_frac <= b[0] and bad_frac <= b[1] and good_bad <= b[2] and ok_rays >= b[3], (ind_frac, bad_frac, good_bad, ok_rays)
+
+
 def test_merge_ties_are_stable():
     L = _lib.lib()
     z = torch.tensor([[0.0, 1.0, 1.0, 2.0]], device=DEV)
@@ -357,6 +457,17 @@ def test_merge_ties_are_stable():
 
 
 # ---------------------------------------------------------------------------------------- render_core on fixed z
+# measured on MI355X (round 2) + margin: fraction of rays with any sample moved by > 1e-3 w.r.t. the reference's z_vals (the
+# sampler is discontinuous in its inputs; the per-step kernels are bit-exact on reference inputs, see the chain test), and the
+# resulting relative difference of the batch-wide gradient_error
+# (measured 0.062 / 0.031 / 0.25 / 0.0 and 1.9e-3 / 2.0e-4 / 5.9e-3 / 0)
+MOVED_BOUND = {"c64_50_5": 0.13, "c64_64_4": 0.10, "c32_32_4_small": 0.35, "c64_64_4_L6": 0.07}
+GE_BOUND = {"c64_50_5": 4e-3, "c64_64_4": 1e-3, "c32_32_4_small": 1.2e-2, "c64_64_4_L6": 1e-3}
+# up-sampling steps on reference inputs (max over steps): (index mismatch fraction, fraction of samples off by > 2e-6, the same among
+# the well-conditioned samples, fraction of rays whose chained final z_vals equal the golden's) - measured on MI355X (round 2) + margin
+# measured: indices 0 / 0 / 0 mismatches; samples 0 / 0 / 3.5 % (one |p| < 1 decision of the d4 case flips); chained rays equal to the
+# golden 97 / 94 / 81 % - the CPU oracle on the same host reaches 97 / 94 / 62 % against the golden recorded on another CPU
+CHAIN_BOUND = {"c64_64_4": (0.002, 0.01, 0.01, 0.90), "c64_50_5": (0.002, 0.01, 0.01, 0.85), "c32_32_4_small": (0.002, 0.07, 0.07, 0.70)}
 G5 = {"c64_50_5": "d8w256L10", "c64_64_4": "d8w256L10", "c32_32_4_small": "d4w128L10", "c64_64_4_L6": "d8w256L6"}
 PER_SAMPLE = ["udf", "weights", "gradients", "gradients_flip", "inside_sphere", "gradient_mag", "mid_z_vals", "dists"]
 
@@ -438,11 +549,15 @@ def test_full_render_vs_reference_golden(case):
     # (per-sample tensors are compared in test_render_core_on_reference_samples, which feeds the reference's own
     # z_vals: with |grad u| ~ 25 and beta ~ 150 one ulp of z already moves a weight by ~1e-3 relative, and the coarse
     # z grid itself is only defined to an ulp - torch.linspace differs between its CPU and CUDA kernels)
-    moved = ((out["z_vals"].cpu() - zref).abs().max(dim=1)[0] > 1e-3).float().mean()
-    assert float(moved) <= 0.6
+    moved = float(((out["z_vals"].cpu() - zref).abs().max(dim=1)[0] > 1e-3).float().mean())
+    ge_err = rel(out["gradient_error"], t(g["out.gradient_error"]))
+    print(f"full render {case}: rays with a sample moved by > 1e-3: {moved:.3f}; gradient_error rel. diff {ge_err:.2e}")
+    assert moved <= MOVED_BOUND[case], moved
     for k in ["variance", "beta", "gamma"]:
         assert rel(out[k], t(g["out." + k])) <= 1e-6, k
-    assert rel(out["gradient_error"], t(g["out.gradient_error"])) <= 2e-2
+    # gradient_error averages (|grad u| - 1)^2 over all samples of the batch, the moved ones included: it sees the re-sampled
+    # intervals directly (on the reference's own z_vals it agrees to 1e-4, test_render_core_on_reference_samples)
+    assert ge_err <= GE_BOUND[case], ge_err
     # single-pass bf16: edge/depth stay within a few percent
     netb, _, _ = mk(G5[case], "bf16")
     rb = mk_renderer(netb, ns, ni, steps)
