@@ -62,6 +62,8 @@ def parse():
     ap.add_argument("--precision", default=os.environ.get("EMAP_BENCH_PRECISION", "f16x3"), choices=list(MODE_DTYPE),
                     help="arithmetic of the MLP GEMMs for `value`; f16x3 is the mode that meets the 1e-4 parity gate")
     ap.add_argument("--eikonal-sync", default="exact", choices=["exact", "local"], help="train mode, N > 1 (emap_amd/parallel.py)")
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+                    help="replay the step from a captured hipGraph (auto: fall back to eager launches if the capture fails)")
     ap.add_argument("--no-other-modes", action="store_true", help="skip the short runs of the other precision modes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
@@ -235,12 +237,30 @@ def main():
         batch = {"rays_o": ro, "rays_d": rd, "near": near, "far": far, "depth_scale": ds, "cos_anneal_ratio": 1.0,
                  "flip_saturation": 0.9, "t_rand": tr}
 
-        def step():
+        def eager_step():
             return trainer.step(batch, te, n_rays_global=rays * world)
     else:
-        def step():
+        def eager_step():
             with torch.no_grad():
                 return r.render(ro, rd, near, far, ds, cos_anneal_ratio=1.0, flip_saturation=0.9, t_rand=tr)
+
+    # hipGraph: the launch chain of a step (15 kernels forward, +8 backward, + torch's elementwise / Adam kernels) replays as one
+    # graph launch.  Multi-rank training keeps eager launches unless --graph on (an RCCL collective inside a captured graph is
+    # not something this build could test on its one-GPU boxes).
+    step, launch = eager_step, "eager"
+    want_graph = a.graph == "on" or (a.graph == "auto" and not (a.mode == "train" and world > 1))
+    if want_graph:
+        try:
+            if a.mode == "train":
+                step = trainer.capture(batch, te, n_rays_global=rays * world)
+            else:
+                step = r.capture(ro, rd, near, far, ds, cos_anneal_ratio=1.0, flip_saturation=0.9, t_rand=tr)
+            launch = "hipGraph replay"
+        except Exception as e:   # pragma: no cover
+            if a.graph == "on":
+                raise
+            step, launch = eager_step, f"eager (graph capture failed: {e!r})"
+            torch.cuda.synchronize()
 
     def barrier():
         if dist is not None:
@@ -274,11 +294,12 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt, med_ms = float(tt[0]), float(tt[1])
 
-    # roofline: a second, short loop with the library's HIP events around the dominant kernel (not in the headline loop)
+    # roofline: a second, short loop (eager launches: events cannot be recorded inside a captured graph) with the library's HIP
+    # events around the dominant kernel - not in the headline loop
     which = 1 if a.mode == "train" else 0
     _lib.check(L.emap_profile_enable(1))
     for _ in range(min(a.steps, 20)):
-        step()
+        eager_step()
     torch.cuda.synchronize()
     _lib.check(L.emap_profile_enable(0))
     kms, kn = C.c_float(), C.c_int()
@@ -315,7 +336,7 @@ def main():
             "config": {"workload": f"{rays} rays/GPU x {S} samples (64 coarse + 64 fine in 4 up-sampling steps), "
                                    f"UDF MLP d=8 w=256 multires=10, {workload}",
                        "rays_per_gpu": rays, "rays_global": rays * world, "samples_per_ray": S, "precision": a.precision,
-                       "mode": a.mode,
+                       "mode": a.mode, "launch": launch,
                        "parallelism": f"dp{world} over rays" + (", no collective in forward" if a.mode == "render" else
                                                                f", {trainer.collectives_per_step} collective(s) per step "
                                                                f"(eikonal_sync={a.eikonal_sync}: "
@@ -349,12 +370,12 @@ def main():
                 try:
                     r.precision = mode
                     for _ in range(5):
-                        step()
+                        eager_step()
                     torch.cuda.synchronize()
                     t1 = time.perf_counter()
                     n_o = max(20, a.steps // 4)
                     for _ in range(n_o):
-                        step()
+                        eager_step()
                     torch.cuda.synchronize()
                     dto = (time.perf_counter() - t1) / n_o
                     pm = measure_parity(dev, mode) if not a.no_parity else {}

@@ -60,6 +60,16 @@ class ParamGrads(C.Structure):
                 ("accumulate", C.c_int32), ("grad_scale", C.c_float), ("reserved", C.c_int32)]
 
 
+class RayDataset(C.Structure):
+    _fields_ = [("edges", C.c_void_p), ("pixel_order", C.c_void_p), ("n_edge", C.c_void_p), ("density", C.c_void_p),
+                ("kinv", C.c_void_p), ("pose", C.c_void_p), ("image_perm", C.c_void_p), ("n_images", C.c_int32), ("H", C.c_int32),
+                ("W", C.c_int32), ("reserved", C.c_int32)]
+
+
+class RayBatch(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("rays_o", "rays_v", "edge", "depth_scale", "ndc_uv", "p_cam", "pixels", "img_idx")]
+
+
 # every symbol include/emap_hip.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
 SYMBOLS = {
@@ -92,6 +102,7 @@ SYMBOLS = {
     "emap_render_bwd_workspace_bytes": (C.c_int, [C.POINTER(NetConfig), C.c_int, C.POINTER(RenderParams), C.POINTER(C.c_size_t)]),
     "emap_render_bwd": (C.c_int, [C.POINTER(NetConfig), _P, C.c_int, C.POINTER(RenderParams), _P, _P, _P, _P, _P, _P, _P,
                                   C.POINTER(CompositeGrads), C.POINTER(ParamGrads), _P, C.c_size_t, _P, _P]),
+    "emap_sample_rays": (C.c_int, [C.POINTER(RayDataset), C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, _P, _P, C.POINTER(RayBatch), _P]),
     "emap_profile_enable": (C.c_int, [C.c_int]),
     "emap_profile_read": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "emap_profile_read_kernel": (C.c_int, [C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]),

@@ -54,6 +54,8 @@ int launch_composite(const float*, const float*, const float*, const float*, con
                      const float*, const float*, float, const EmapCompositeOut*, float*, int32_t*, hipStream_t);
 int launch_embed(const float*, int64_t, int, float*, hipStream_t);
 void linspace_host(float, float, int, float*);
+int launch_sample_rays(const EmapRayDataset*, int, int, int, uint64_t, uint64_t, uint64_t*, const int64_t*, const EmapRayBatch*,
+                       hipStream_t);
 int launch_composite_bwd(const float*, const float*, const float*, const float*, const float*, const float*, int, int,
                          const float*, const EmapRenderParams*, const EmapCompositeGrads*, float*, float*, float*, uint32_t*,
                          hipStream_t);
@@ -477,6 +479,11 @@ int emap_render_bwd(const EmapNetConfig* cfg, const void* packed, int prec, cons
     memset(&fin, 0, sizeof(fin));
     fin.rays_o = rays_o; fin.rays_d = rays_d; fin.z = z_vals; fin.n_per_ray = S; fin.mid = 1; fin.sample_dist = sample_dist_dev;
     return run_vjp(L, packed, prec, fin, (int64_t)N * S, d_udf, d_grad, out, pl, vws, err_flags, st);
+}
+
+int emap_sample_rays(const EmapRayDataset* ds, int img_idx, int batch, int importance, uint64_t seed, uint64_t offset,
+                     uint64_t* counter_dev, const int64_t* pixels_in, const EmapRayBatch* out, void* stream) {
+    return launch_sample_rays(ds, img_idx, batch, importance, seed, offset, counter_dev, pixels_in, out, static_cast<hipStream_t>(stream));
 }
 
 int emap_null_direction(const float* grads, int64_t n, int k, float* dir, void* stream) {

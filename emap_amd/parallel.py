@@ -100,8 +100,9 @@ class Trainer:
         dev = self.flat.data.device
         if fused_adam is None:
             fused_adam = dev.type == "cuda"
+        # capturable: the step counters live on the device, so a whole step can be captured in a hipGraph (capture())
         self.optimizer = torch.optim.Adam([{"params": [self.p_geo], "lr": lr_geo}, {"params": [self.p_sc]}], lr=lr,
-                                          **({"fused": True} if fused_adam else {}))
+                                          **({"fused": True, "capturable": True} if fused_adam else {}))
         self.collectives_per_step = 0 if _world(group) == 1 else (2 if eikonal_sync == "exact" else 1)
         # "local": every rank normalises by its own mask sums, so the sum over ranks needs the 1/world of a mean of means
         k = 1.0 / _world(group) if eikonal_sync == "local" else 1.0
@@ -153,6 +154,38 @@ class Trainer:
         loss = edge_loss + self.igr_weight * stats[2] / (stats[0] + 1e-5) + self.igr_ns_weight * stats[3] / (stats[1] + 1e-5)
         self.last_stats = torch.stack([loss, edge_loss])
         return self.last_stats
+
+
+    def capture(self, rays: Dict, true_edge: torch.Tensor, n_rays_global: Optional[int] = None, warmup: int = 3):
+        """Capture one whole step (pack -> render forward -> statistics -> HIP backward -> [all-reduce] -> Adam) for this batch
+        shape in a hipGraph and return ``replay(rays=None, true_edge=None) -> [loss, edge_loss]`` (device tensor, static).
+        New rays / targets are copied into the graph's static buffers before the replay.  `warmup` real steps are taken first
+        (workspaces, function attributes, Adam state must exist before capturing)."""
+        dev = self.flat.data.device
+        static = {k: (v.detach().clone() if isinstance(v, torch.Tensor) else v) for k, v in rays.items()}
+        te = true_edge.detach().clone()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(max(warmup, 1)):
+                self.step(static, te, n_rays_global)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = self.step(static, te, n_rays_global)
+
+        def replay(rays: Optional[Dict] = None, true_edge: Optional[torch.Tensor] = None):
+            if rays is not None:
+                for k, v in rays.items():
+                    if isinstance(v, torch.Tensor):
+                        static[k].copy_(v)
+            if true_edge is not None:
+                te.copy_(true_edge)
+            graph.replay()
+            return out
+
+        replay.graph = graph
+        return replay
 
 
 # ---------------------------------------------------------------------------------------------

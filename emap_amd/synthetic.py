@@ -124,3 +124,33 @@ def make_true_edge(n_rays: int, seed: int = 11, dtype=torch.float32):
     on = rng.uniform(size=(n_rays, 1)) < 0.1
     val = rng.uniform(0.5, 1.0, size=(n_rays, 1))
     return torch.tensor(on * val, dtype=dtype)
+
+
+def make_scene(n_images: int = 8, H: int = 100, W: int = 120, seed: int = 3, radius: float = 3.0, fov_deg: float = 50.0):
+    """Synthetic stand-in for an EMAP dataset directory (no datasets travel): `meta` in the wire format of meta_data.json
+    (reference src/dataset/dataset.py:66-104: scene_box{near,far,radius,aabb}, height, width, frames[{intrinsics 4x4,
+    camtoworld 4x4, rgb_path}]) and edge maps (n_images,H,W,1) in [0,1] as cv.imread(...,0)/255 would give them (:133-135):
+    a few anti-aliased line segments per image on a dark background."""
+    g = np.random.Generator(np.random.PCG64(seed))
+    f = 0.5 * W / np.tan(np.deg2rad(fov_deg) / 2)
+    K = np.array([[f, 0, (W - 1) / 2, 0], [0, f, (H - 1) / 2, 0], [0, 0, 1, 0], [0, 0, 0, 1]], dtype=np.float64)
+    frames, edges = [], np.zeros((n_images, H, W, 1), dtype=np.float32)
+    ys, xs = np.mgrid[0:H, 0:W]
+    for i in range(n_images):
+        th, ph = 2 * np.pi * i / n_images, 0.3 * np.sin(1.7 * i)
+        c = radius * np.array([np.cos(th) * np.cos(ph), np.sin(ph), np.sin(th) * np.cos(ph)])
+        zax = -c / np.linalg.norm(c)
+        xax = np.cross([0.0, 1.0, 0.0], zax); xax /= np.linalg.norm(xax)
+        yax = np.cross(zax, xax)
+        c2w = np.eye(4); c2w[:3, 0], c2w[:3, 1], c2w[:3, 2], c2w[:3, 3] = xax, yax, zax, c
+        frames.append({"intrinsics": K.tolist(), "camtoworld": c2w.tolist(), "rgb_path": f"{i:04d}.png"})
+        img = np.zeros((H, W))
+        for _ in range(4):
+            x0, y0, x1, y1 = g.uniform(0, W), g.uniform(0, H), g.uniform(0, W), g.uniform(0, H)
+            t = np.clip(((xs - x0) * (x1 - x0) + (ys - y0) * (y1 - y0)) / ((x1 - x0) ** 2 + (y1 - y0) ** 2 + 1e-9), 0, 1)
+            d = np.hypot(xs - (x0 + t * (x1 - x0)), ys - (y0 + t * (y1 - y0)))
+            img = np.maximum(img, np.clip(1.5 - d, 0, 1) * g.uniform(0.5, 1.0))
+        edges[i, :, :, 0] = np.round(img * 255) / 255
+    meta = {"scene_box": {"near": 0.05, "far": 6.0, "radius": 1.0, "aabb": [[-1, -1, -1], [1, 1, 1]]}, "height": H, "width": W,
+            "frames": frames}
+    return meta, edges

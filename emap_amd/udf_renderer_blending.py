@@ -292,6 +292,13 @@ class UDFRendererBlending:
             "eikonal_sums": v["scalars"][3:7],
         }
 
+    def capture(self, rays_o, rays_d, near, far, depth_scale, cos_anneal_ratio=None, background_rgb=None, flip_saturation=0,
+                t_rand=None, reduced=False):
+        """Capture one inference render of this batch shape in a hipGraph (SURVEY par. 7.1 step 8 / H3: the 15 dependent launches
+        of emap_render_fwd replay as ONE graph launch).  Returns a RenderGraph; see its docstring."""
+        return RenderGraph(self, rays_o, rays_d, near, far, depth_scale, cos_anneal_ratio, background_rgb, flip_saturation, t_rand,
+                           reduced)
+
     def render_reduced(self, rays_o, rays_d, near, far, depth_scale, cos_anneal_ratio=None, perturb_overwrite=-1,
                        background_rgb=None, flip_saturation=0, t_rand=None):
         """Inference-only render that writes just the per-ray results (edge, depth, normals, weight_sum): the launch mode of
@@ -302,3 +309,58 @@ class UDFRendererBlending:
         N = call["N"]
         return {"edge": v["edge"].view(N, 1), "depth": v["depth"].view(N, 1), "normals": v["normals"].view(N, 3),
                 "weight_sum": v["weight_sum"].view(N, 1), "gradient_error": v["scalars"][0], "sparse_error": v["scalars"][2]}
+
+
+class RenderGraph:
+    """A captured ``render()`` (inference): static input buffers + one hipGraph of the whole launch chain.
+
+        g = renderer.capture(rays_o, rays_d, near, far, depth_scale, cos_anneal_ratio=1.0, t_rand=t)   # shapes are fixed here
+        out = g(rays_o2, rays_d2, near2, far2, depth_scale2, t_rand=t2)     # copies into the static buffers, replays, returns
+
+    The returned dict aliases the graph's static output buffers: consume (or clone) it before the next replay.  Scalars that
+    the kernels read from device memory (variance / beta / gamma, the packed weights) are read at replay time, so parameter
+    updates are seen as long as ``UDFNetwork.packed()`` is refreshed by the caller after an optimizer step (it is a kernel
+    launch outside the graph).  cos_anneal_ratio / flip_saturation / background are baked in at capture.
+    The jitter must be passed explicitly (`t_rand`, (N,1) in [-0.5, 0.5)): the reference's CPU-generator draw plus its
+    host-to-device copy (udf_renderer_blending.py:719) cannot be part of a device graph."""
+
+    def __init__(self, r, rays_o, rays_d, near, far, depth_scale, cos_anneal_ratio, background_rgb, flip_saturation, t_rand, reduced):
+        _lib.require_cuda(rays_o, "rays_o")
+        if r.perturb > 0 and t_rand is None:
+            raise ValueError("RenderGraph: pass t_rand explicitly (or construct the renderer with perturb=0)")
+        self.r = r
+        dev = rays_o.device
+        N = len(rays_o)
+        st = lambda x: None if x is None else _lib.f32c(x.detach().to(dev)).clone()
+        self.ro, self.rd, self.ds, self.tr = st(rays_o), st(rays_d), st(depth_scale), st(t_rand)
+        if isinstance(near, torch.Tensor):
+            self.near, self.far = st(near.reshape(-1).expand(N)), st(far.reshape(-1).expand(N))
+        else:
+            self.near, self.far = float(near), float(far)
+        self.kw = dict(cos_anneal_ratio=cos_anneal_ratio, background_rgb=background_rgb, flip_saturation=flip_saturation)
+        self.reduced = reduced
+        r.udf_network.packed(r.precision)                        # pack outside the capture
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(2):                                    # allocate workspaces / set function attributes before capturing
+                self._run()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph):
+            self.out = self._run()
+
+    def _run(self):
+        r = self.r
+        f = r.render_reduced if self.reduced else r.render
+        return f(self.ro, self.rd, self.near, self.far, self.ds, perturb_overwrite=(-1 if self.tr is not None else 0), t_rand=self.tr,
+                 **self.kw)
+
+    def __call__(self, rays_o=None, rays_d=None, near=None, far=None, depth_scale=None, t_rand=None):
+        for dst, src in ((self.ro, rays_o), (self.rd, rays_d), (self.ds, depth_scale), (self.tr, t_rand)):
+            if src is not None:
+                dst.copy_(src.reshape(dst.shape))
+        if near is not None and isinstance(self.near, torch.Tensor):
+            self.near.copy_(near.reshape(-1).expand_as(self.near)); self.far.copy_(far.reshape(-1).expand_as(self.far))
+        self.graph.replay()
+        return self.out

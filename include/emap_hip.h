@@ -241,6 +241,44 @@ int emap_render_bwd(const EmapNetConfig* cfg, const void* packed, int prec, cons
                     const float* sample_dist_dev, const EmapCompositeGrads* g, const EmapParamGrads* out, void* workspace,
                     size_t workspace_bytes, int32_t* err_flags, void* stream);
 
+/* ---- on-device ray / pixel sampler (SURVEY par. 8 f3) ---------------------------------------------
+ * Replaces Dataset.gen_random_rays_patches_at (src/dataset/dataset.py:222-307): pixel draw (uniform, or 50 % uniform + 50 %
+ * edge-weighted when importance != 0, :236-263), edge look-up (:270), p = K^-1 [x,y,1] (:272-277), rays_v = R p/|p| (:279-283),
+ * rays_o = t (:284-286), depth_scale (:280), ndc uv (:265-267) - one launch, everything resident on the device.
+ * The dataset is uploaded once: edges (n_images,H,W) in [0,1] (cv.imread(...,0)/255, :133-135), the inverse intrinsics'
+ * upper 3x3 (:119) and the 4x4 camera-to-world poses (:86,121), row-major.  For importance sampling additionally, per image:
+ * pixel_order (H*W int32: row-major pixel ids, those with edge > 0.1 first), n_edge (their count) and density (the image's
+ * mean edge value).
+ * Random numbers: Philox4x32-10 with key `seed`, stream = step, index = ray.  step = *counter_dev when counter_dev != NULL
+ * (the kernel chain then increments it: the sampler can live inside a captured graph), else `offset`.
+ * img_idx < 0 selects image_perm[step % n_images] (or step % n_images when image_perm is NULL) on the device.
+ * pixels_in ((N,2) int64 x,y; may be NULL) bypasses the draw: the deterministic part, used by the parity tests.
+ * Any output pointer may be NULL. */
+typedef struct EmapRayDataset {
+    const float* edges;          /* (n_images,H,W)   */
+    const int32_t* pixel_order;  /* (n_images,H*W) or NULL */
+    const int32_t* n_edge;       /* (n_images) or NULL     */
+    const float* density;        /* (n_images) or NULL     */
+    const float* kinv;           /* (n_images,3,3)   */
+    const float* pose;           /* (n_images,4,4)   */
+    const int32_t* image_perm;   /* (n_images) or NULL (runner_udf.py:79-82 image_perm) */
+    int32_t n_images, H, W, reserved;
+} EmapRayDataset;
+
+typedef struct EmapRayBatch {
+    float* rays_o;       /* (N,3) */
+    float* rays_v;       /* (N,3) */
+    float* edge;         /* (N)   */
+    float* depth_scale;  /* (N)   */
+    float* ndc_uv;       /* (N,2) */
+    float* p_cam;        /* (N,3)  rays_norm_XYZ_cam */
+    int64_t* pixels;     /* (N,2)  x,y */
+    int32_t* img_idx;    /* (1)    the image the batch came from */
+} EmapRayBatch;
+
+int emap_sample_rays(const EmapRayDataset* ds, int img_idx, int batch, int importance, uint64_t seed, uint64_t offset,
+                     uint64_t* counter_dev, const int64_t* pixels_in, const EmapRayBatch* out, void* stream);
+
 /* ---- dense-grid extraction (SURVEY par. 8 f2) ----------------------------------------------------
  * emap_null_direction : `_, _, vh = torch.linalg.svd(grad_ld); F.normalize(vh[:, -1, :])` of get_udf_normals_grid /
  *                       get_udf_normals_slow (src/edge_extraction/extract_pointcloud.py:86-88, 177-179): per point the unit

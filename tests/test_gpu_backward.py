@@ -296,3 +296,80 @@ def test_network_methods_under_autograd(name):
     phi = (uo * wu.double()).sum() + (go.unsqueeze(1) * wg.double()).sum()
     ref = dict(zip(st.keys(), torch.autograd.grad(phi, list(st.values()))))
     _cmp({k: p.grad.cpu() for k, p in net.named_parameters()}, ref, 1e-3, name)
+
+
+def _fresh(prec="f16x3", name="d8w256L10", ns=64, ni=64, steps=4):
+    net, state, cfg = mk(name, prec)
+    r = mk_renderer(net, ns, ni, steps)
+    return net, r
+
+
+def test_trainer_step_equals_autograd_step_and_graph_replay_equals_eager():
+    """emap_amd.parallel.Trainer (native step: flat buffers, no autograd graph) produces the gradients of the drop-in path
+    (render() + EdgeLoss + loss.backward()), and a hipGraph replay of the step produces the parameters of eager steps."""
+    from emap_amd import synthetic
+    from emap_amd.parallel import Trainer
+    N = 256
+    ro, rd, near, far, ds = [v.to(DEV) for v in synthetic.make_rays(N, seed=4)]
+    te = synthetic.make_true_edge(N, seed=5).to(DEV)
+    tr = synthetic.make_t_rand(N, seed=6).to(DEV)
+    batch = {"rays_o": ro, "rays_d": rd, "near": near, "far": far, "depth_scale": ds, "cos_anneal_ratio": 1.0, "flip_saturation": 0.9,
+             "t_rand": tr}
+    # (1) autograd path
+    net_a, r_a = _fresh()
+    out = r_a.render(ro, rd, near, far, ds, cos_anneal_ratio=1.0, flip_saturation=0.9, t_rand=tr)
+    loss = emap_amd.EdgeLoss("mse")(out["edge"], te) * 1.0 + out["gradient_error"] * 0.1
+    loss.backward()
+    ga = torch.cat([p.grad.reshape(-1) for p in net_a.parameters()] +
+                   [r_a.deviation_network.variance.grad, r_a.beta_network.beta.grad, r_a.beta_network.gamma.grad])
+    # (2) native step (lr 0 so that the parameters stay comparable)
+    net_b, r_b = _fresh()
+    tb = Trainer(r_b, lr_geo=0.0, lr=0.0, edge_weight=1.0, igr_weight=0.1, igr_ns_weight=0.0)
+    stats = tb.step(batch, te)
+    torch.cuda.synchronize()
+    gb = tb.flat.grad[:tb.flat.numel]
+    assert float(stats[0]) == pytest.approx(float(loss), rel=1e-5)
+    assert float((ga - gb).abs().max()) <= 1e-6 * float(ga.abs().max())
+    # (3) three eager steps vs warm-up + graph replays with real learning rates
+    net_c, r_c = _fresh()
+    tc = Trainer(r_c, lr_geo=1e-4, lr=5e-4, igr_weight=0.1)
+    for _ in range(5):
+        tc.step(batch, te)
+    net_d, r_d = _fresh()
+    td = Trainer(r_d, lr_geo=1e-4, lr=5e-4, igr_weight=0.1)
+    replay = td.capture(batch, te, warmup=3)        # 3 eager steps + the captured one is NOT executed during capture
+    s1 = replay()
+    s2 = replay(batch, te)
+    torch.cuda.synchronize()
+    r_d.check_errors()
+    assert torch.isfinite(s2).all()
+    d = float((tc.flat.data - td.flat.data).abs().max())
+    assert d <= 1e-6, d
+
+
+def test_render_graph_replay_equals_eager_render():
+    from emap_amd import synthetic
+    net, r = _fresh()
+    N = 512
+    ro, rd, near, far, ds = [v.to(DEV) for v in synthetic.make_rays(N, seed=1)]
+    tr = synthetic.make_t_rand(N, seed=7).to(DEV)
+    with torch.no_grad():
+        ref = r.render(ro, rd, near, far, ds, cos_anneal_ratio=1.0, flip_saturation=0.9, t_rand=tr)
+        ref = {k: v.clone() for k, v in ref.items()}
+    g = r.capture(ro, rd, near, far, ds, cos_anneal_ratio=1.0, flip_saturation=0.9, t_rand=tr)
+    out = g()
+    torch.cuda.synchronize()
+    for k in ("edge", "depth", "normals", "weights", "z_vals", "udf", "gradients"):
+        assert torch.equal(out[k], ref[k]), k
+    # new rays through the same graph
+    ro2, rd2, near2, far2, ds2 = [v.to(DEV) for v in synthetic.make_rays(N, seed=2)]
+    with torch.no_grad():
+        ref2 = r.render(ro2, rd2, near2, far2, ds2, cos_anneal_ratio=1.0, flip_saturation=0.9, t_rand=tr)
+        ref2 = {k: v.clone() for k, v in ref2.items()}
+    out2 = g(ro2, rd2, near2, far2, ds2, t_rand=tr)
+    torch.cuda.synchronize()
+    assert torch.equal(out2["edge"], ref2["edge"]) and torch.equal(out2["z_vals"], ref2["z_vals"])
+    gr = r.capture(ro, rd, near, far, ds, cos_anneal_ratio=1.0, flip_saturation=0.9, t_rand=tr, reduced=True)
+    o3 = gr()
+    torch.cuda.synchronize()
+    assert torch.equal(o3["edge"], ref["edge"]) and torch.equal(o3["normals"], ref["normals"])

@@ -582,11 +582,12 @@ def test_perturb_path_and_float_near_far():
         assert rel(o["edge"], t(g[ke])) <= 1e-4
 
 
-def test_north_star_batch_properties():
-    """512 rays x 128 samples (the benchmark batch): size-independent invariants of the path."""
-    net, state, cfg = mk("d8w256L10", "f16x3")
+@pytest.mark.parametrize("N,prec,tol", [(512, "f16x3", 1e-3), (1024, "f16x3", 1e-3), (1024, "bf16", 0.1), (4096, "f16x3", 1e-3)])
+def test_north_star_batch_properties(N, prec, tol):
+    """The benchmark batch (512 rays x 128 samples), BASELINE config C2's exact shape (1024 x 128, in f16x3 and in the bf16 it
+    names) and C4's global batch (4096 x 128): size-independent invariants of the path."""
+    net, state, cfg = mk("d8w256L10", prec)
     r = mk_renderer(net, 64, 64, 4)
-    N = 512
     ro, rd, near, far, ds = [v.to(DEV) for v in synthetic.make_rays(N, seed=1)]
     tr = synthetic.make_t_rand(N).to(DEV)
     with torch.no_grad():
@@ -614,7 +615,7 @@ def test_north_star_batch_properties():
     ref = O.render(state, cfg, O.RenderConfig(64, 64, 4), ro[sl].cpu(), rd[sl].cpu(), near[sl].cpu(), far[sl].cpu(), ds[sl].cpu(),
                    torch.tensor([0.3]), torch.tensor([0.5]), torch.tensor([0.3]), cos_anneal_ratio=1.0, t_rand=tr[sl].cpu().view(-1, 1),
                    flip_saturation=0.9)
-    assert rel(o1["edge"][sl], ref["edge"]) <= 1e-3 and rel(o1["depth"][sl], ref["depth"]) <= 1e-3
+    assert rel(o1["edge"][sl], ref["edge"]) <= tol and rel(o1["depth"][sl], ref["depth"]) <= tol
 
 
 # ---------------------------------------------------------------------------------------- extraction queries (par. 8 f2)
