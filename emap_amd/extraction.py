@@ -2,9 +2,12 @@
 
 Mirror of ``get_udf_normals_grid`` (src/edge_extraction/extract_pointcloud.py:5-95): same arguments, same return tuple,
 same jitter draws (one ``torch.randn((n, sampling_N, 3), device=device)`` per ``max_batch`` chunk, in the same order), but
-  * when ``func`` / ``func_grad`` are ``UDFNetwork.udf`` / ``UDFNetwork.gradient`` of this package, the grid, the thresholded
-    subset and all jittered neighbourhoods are evaluated in a few large launches (the reference issues N^3/4096 + 51 x
-    n/4096 launches of 4096 points; large gradient launches run the reverse-sweep kernel),
+  * the grid, the thresholded subset and all jittered neighbourhoods are evaluated in a few launches of up to 2^20 points
+    instead of the reference's N^3/4096 + 51 x n/4096 calls of 4096 points - for ANY ``func`` / ``func_grad``, in particular the
+    closure ``Runner_UDF.extract_edge`` passes (runner_udf.py:520-527: ``udf_network.gradient`` followed by a normalisation).
+    Both callables act point by point, so the chunk size cannot change a result; it only decides whether the field kernels
+    see 4096 points (a latency-bound launch) or a million (large gradient launches run the reverse-sweep kernel).  When the
+    callables are this package's bound ``UDFNetwork.udf`` / ``.gradient`` the wrappers are skipped as well,
   * the line direction ``F.normalize(torch.linalg.svd(grad_ld)[2][:, -1, :])`` (:86-88) is one HIP kernel over the
     3x3 matrices G^T G (``emap_null_direction``): no 50x3 SVD batch.
 There is no CPU fallback: tensors must live on the GPU and libemap_hip.so must be loadable.
@@ -67,7 +70,7 @@ def get_udf_normals_grid(func, func_grad, N, udf_threshold, is_linedirection=Fal
         if net is not None:
             df = _eval(lambda p: net.hip_udf(p, with_grad=False)[0], pts, _BIG)
         else:
-            df = _eval(lambda p: func(p)[0].detach(), pts, max_batch)
+            df = _eval(lambda p: func(p)[0].detach(), pts, _BIG)
         samples[:, 3:4] = df
 
         norm_idx = torch.where(samples[:, 3] < udf_threshold)[0]            # :64-65
@@ -75,7 +78,7 @@ def get_udf_normals_grid(func, func_grad, N, udf_threshold, is_linedirection=Fal
         if net is not None:
             grad = _eval(lambda p: net.hip_udf(p, with_grad=True)[1], sub, _BIG).reshape(-1, 1, 3) if len(norm_idx) else sub.reshape(-1, 1, 3)
         else:
-            grad = _eval(lambda p: func_grad(p).detach(), sub, max_batch) if len(norm_idx) else sub.reshape(-1, 1, 3)
+            grad = _eval(lambda p: func_grad(p).detach(), sub, _BIG) if len(norm_idx) else sub.reshape(-1, 1, 3)
         # the reference normalises the (P,1,3) gradient along dim=1 - the singleton - i.e. per component (:71)
         samples[norm_idx, 4:7] = -torch.nn.functional.normalize(grad, dim=1)[:, 0]
 
@@ -88,7 +91,7 @@ def get_udf_normals_grid(func, func_grad, N, udf_threshold, is_linedirection=Fal
             if net is not None:
                 grad_ld = _eval(lambda p: net.hip_udf(p, with_grad=True)[1], ld_pts, _BIG)
             else:
-                grad_ld = _eval(lambda p: func_grad(p).detach().reshape(-1, 3), ld_pts, max_batch * sampling_N)
+                grad_ld = _eval(lambda p: func_grad(p).detach().reshape(-1, 3), ld_pts, _BIG)
             samples[norm_idx, 8:11] = null_direction(grad_ld.reshape(len(norm_idx), sampling_N, 3))
 
     df_values = samples[:, 3].reshape(N, N, N)
@@ -116,8 +119,8 @@ def get_udf_normals_slow(func, func_grad, voxel_size, xyz, is_linedirection, sam
             df = torch.cat([r[0] for r in res]) if n else pts[:, :1]
             grad = torch.cat([r[1] for r in res]) if n else pts
         else:
-            df = _eval(lambda p: func(p)[0].detach(), pts, max_batch)
-            grad = _eval(lambda p: func_grad(p).detach()[:, 0], pts, max_batch)
+            df = _eval(lambda p: func(p)[0].detach(), pts, _BIG)
+            grad = _eval(lambda p: func_grad(p).detach()[:, 0], pts, _BIG)
         samples[:, 3] = df.squeeze(-1)
         samples[:, 4:7] = -torch.nn.functional.normalize(grad, dim=1)                     # :158-160
         if is_linedirection and n:
@@ -128,6 +131,6 @@ def get_udf_normals_slow(func, func_grad, voxel_size, xyz, is_linedirection, sam
             if net is not None:
                 grad_ld = _eval(lambda p: net.hip_udf(p, with_grad=True)[1], ld_pts, _BIG)
             else:
-                grad_ld = _eval(lambda p: func_grad(p.float()).detach()[:, 0], ld_pts, max_batch * sampling_N)
+                grad_ld = _eval(lambda p: func_grad(p.float()).detach()[:, 0], ld_pts, _BIG)
             samples[:, 7:10] = null_direction(grad_ld.reshape(n, sampling_N, 3))
     return samples[:, 3], samples[:, 4:7], samples[:, 7:10], samples

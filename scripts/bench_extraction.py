@@ -53,6 +53,12 @@ def main():
         thr = float(df.reshape(-1)[torch.randperm(N ** 3, device=dev)[:200000]].quantile(a.frac))
         t_all, out = ev_time(lambda: extraction.get_udf_normals_grid(net.udf, net.gradient, N, thr, True, device=dev), reps=2)
         n_thr = int((out[0].reshape(-1) < thr).sum())
+
+        def func_grad(xyz):                                   # the closure of Runner_UDF.extract_edge (runner_udf.py:522-526)
+            gradients = net.gradient(xyz)
+            gradients_mag = torch.linalg.norm(gradients, ord=2, dim=-1, keepdim=True)
+            return gradients / (gradients_mag + 1e-5)
+        t_closure, _ = ev_time(lambda: extraction.get_udf_normals_grid(net.udf, func_grad, N, thr, True, device=dev), reps=2)
         pts = out[3][:, :3].contiguous()
         t_val, _ = ev_time(lambda: net.hip_udf(pts, with_grad=False))
         big = torch.rand(1 << 20, 3, device=dev) * 2 - 1
@@ -65,6 +71,7 @@ def main():
         "config": {"workload": f"{N}^3 grid, threshold at the {a.frac:.0%} quantile ({n_thr} points), sampling_N=50, f16x3",
                    "mlp_evaluations": N ** 3 + n_thr * 51},
         "seconds": t_all, "mlp_evals_per_s": (N ** 3 + n_thr * 51) / t_all,
+        "seconds_through_the_runners_closure": t_closure, "points_per_s_through_the_runners_closure": N ** 3 / t_closure,
         "parts": {"value_pass_points_per_s": N ** 3 / t_val, "grad_points_per_s": (1 << 20) / t_grad,
                   "null_direction_points_per_s": n_thr / t_nd},
         "roofline_null_direction": {"bound": "hbm", "achieved": nd_bytes / t_nd / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -333,6 +333,30 @@ def g10_extraction():
     finally:
         torch.Tensor.cuda = orig_cuda
     out.update(xyz=xyz, slow_df=dfs, slow_normals=normals, slow_ld=lds, slow_noise=torch.cat(list(noise2)))
+
+    # The call pattern of the real caller: Runner_UDF.extract_edge hands get_pointcloud_from_udf a CLOSURE that normalises the
+    # gradient (runner_udf.py:520-527) - the runner module itself cannot be imported here (pyhocon, cv2, ...), so the
+    # closure is restated verbatim around the reference's UDFNetwork.  Same seeds -> same jitter draws as above.
+    def func_grad(xyz_):
+        gradients = net.gradient(xyz_)
+        gradients_mag = torch.linalg.norm(gradients, ord=2, dim=-1, keepdim=True)
+        gradients_norm = gradients / (gradients_mag + 1e-5)
+        return gradients_norm
+
+    torch.manual_seed(99)
+    get_udf_normals_grid(net.udf, func_grad, N, -1.0, False, device="cpu")
+    _, c_ld, c_vecs, _, _ = get_udf_normals_grid(net.udf, func_grad, N, thr, True, sampling_N=50, sampling_delta=0.005,
+                                                 max_batch=256, device="cpu")
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        torch.manual_seed(99)
+        with capture("randn") as noise3:
+            _, c_normals, c_lds, _ = get_udf_normals_slow(net.udf, func_grad, None, xyz, True, sampling_N=50, sampling_delta=0.005,
+                                                          max_batch=128, device="cpu")
+    finally:
+        torch.Tensor.cuda = orig_cuda
+    out.update(closure_ld=c_ld, closure_vecs=c_vecs, closure_slow_normals=c_normals, closure_slow_ld=c_lds,
+               closure_slow_noise=torch.cat(list(noise3)))
     save("g10_extraction", **out)
 
 

@@ -712,6 +712,48 @@ def test_extraction_grid_vs_reference_golden():
     assert float(_dir_err_each(ld2.reshape(-1, 3).cpu()[both], ld.reshape(-1, 3).cpu()[both])[ok].max()) <= 2e-3
 
 
+def test_extraction_through_the_runners_closure():
+    """The call pattern of the real caller: Runner_UDF.extract_edge passes `udf_network.udf` and a CLOSURE that normalises
+    `udf_network.gradient` (runner_udf.py:520-527).  Goldens recorded from the reference functions with that closure.  Also
+    checks that the closure is driven with large launches (a handful of calls, not n/4096)."""
+    from emap_amd.extraction import get_udf_normals_slow, get_udf_normals_grid
+    g = load_golden("g10_extraction")
+    net, state, cfg = mk("d8w256L10", "f16x3")
+    calls = []
+
+    def func_grad(xyz):                                     # runner_udf.py:522-526, verbatim
+        calls.append(int(xyz.shape[0]))
+        gradients = net.gradient(xyz)
+        gradients_mag = torch.linalg.norm(gradients, ord=2, dim=-1, keepdim=True)
+        gradients_norm = gradients / (gradients_mag + 1e-5)
+        return gradients_norm
+
+    xyz = t(g["xyz"])
+    df, normals, ld, samples = get_udf_normals_slow(net.udf, func_grad, None, xyz, True, sampling_N=50, sampling_delta=0.005,
+                                                    max_batch=128, device=DEV, noise=t(g["closure_slow_noise"]))
+    assert calls == [300, 300 * 50]                          # two launches; the reference's schedule is 3 + 118 calls of <= 128 x 50 points
+    assert rel(df, t(g["slow_df"])) <= 1e-4
+    assert float((normals.cpu() - t(g["closure_slow_normals"])).abs().max()) <= 2e-4
+    ld_pts = (xyz.unsqueeze(1) + 0.005 * t(g["closure_slow_noise"])).reshape(-1, 3)
+    gr = O.udf_gradient_autograd(state, cfg, ld_pts)[:, 0]
+    gr = (gr / (torch.linalg.norm(gr, dim=-1, keepdim=True) + 1e-5)).reshape(300, 50, 3)
+    sv = torch.linalg.svdvals(gr.double())
+    ok = ((sv[:, 1] - sv[:, 2]) / sv[:, 0] > 1e-3)
+    assert int(ok.sum()) >= 150
+    assert float(_dir_err_each(ld.cpu(), t(g["closure_slow_ld"]))[ok].max()) <= 2e-3
+    # the same closure through the dense-grid routine: one launch per stage for 12^3 points
+    calls.clear()
+    N, thr = int(g["N"]), float(g["thr"])
+    dfg, ldg, vecs, _, _ = get_udf_normals_grid(net.udf, func_grad, N, thr, True, sampling_N=50, sampling_delta=0.005, max_batch=256,
+                                                device=DEV)
+    n_thr = int((dfg.reshape(-1) < thr).sum())
+    assert calls == [n_thr, n_thr * 50]
+    gmask = t(g["df"]).reshape(-1) < thr
+    both = gmask & (dfg.reshape(-1).cpu() < thr)
+    v, gv = vecs.reshape(-1, 3).cpu()[both], t(g["closure_vecs"]).reshape(-1, 3)[both]
+    assert float((v != gv).float().mean()) <= 0.01
+
+
 # ---------------------------------------------------------------------------------------- full-image path (par. 8 f4)
 @pytest.mark.parametrize("case", list(G5))
 def test_reduced_output_render_vs_reference_golden(case):
