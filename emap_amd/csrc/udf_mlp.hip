@@ -298,13 +298,11 @@ int launch_mlp_f16x3(const NetLayout&, const void*, const PointSource&, int64_t,
 // EMAP_MLP_KERNEL=classic|fs|fs2 forces one forward-mode variant, EMAP_GRAD_MODE=fwd|rev picks how d(udf)/dx is
 // computed (A/B measurements).
 static int mlp_variant(const NetLayout& L, int prec, int64_t P, bool grad) {
-    static int forced = -2, grad_mode = -2;
-    if (forced == -2) {
-        const char* e = getenv("EMAP_MLP_KERNEL");
-        forced = !e ? -1 : (!strcmp(e, "classic") ? 0 : (!strcmp(e, "fs") ? 1 : (!strcmp(e, "fs2") ? 2 : -1)));
-        const char* gm = getenv("EMAP_GRAD_MODE");
-        grad_mode = !gm ? -1 : (!strcmp(gm, "fwd") ? 0 : (!strcmp(gm, "rev") ? 1 : -1));
-    }
+    // read on every call (two getenv, ~100 ns): the tests and the A/B scripts flip them inside one process
+    const char* e = getenv("EMAP_MLP_KERNEL");
+    const int forced = !e ? -1 : (!strcmp(e, "classic") ? 0 : (!strcmp(e, "fs") ? 1 : (!strcmp(e, "fs2") ? 2 : -1)));
+    const char* gm = getenv("EMAP_GRAD_MODE");
+    const int grad_mode = !gm ? -1 : (!strcmp(gm, "fwd") ? 0 : (!strcmp(gm, "rev") ? 1 : -1));
     // reverse mode halves the MFMA work of a grad launch but a tile is two dependent sweeps: it wins once most CUs have a
     // workgroup (measured crossover: f16x3 between 8k and 12k points, single-pass modes at 16k).  bf16x3 stays on the
     // forward-mode kernel: its reverse instantiation is not run-to-run deterministic with two workgroups per CU (open issue,

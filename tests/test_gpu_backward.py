@@ -373,3 +373,25 @@ def test_render_graph_replay_equals_eager_render():
     o3 = gr()
     torch.cuda.synchronize()
     assert torch.equal(o3["edge"], ref["edge"]) and torch.equal(o3["normals"], ref["normals"])
+
+
+@pytest.mark.parametrize("prec", ["f16x3", "bf16x3", "f16", "bf16"])
+def test_large_launches_are_bit_stable_run_to_run(prec, monkeypatch):
+    """Determinism stress (DESIGN.md par. 3.1): repeated launches of the big kernels on the same inputs are bit-identical -
+    the training backward (sweep + weight-gradient GEMMs + reduction) in all four modes, the reverse-sweep value+gradient kernel
+    in the three modes it is the default for.  (Its bf16x3 instantiation is NOT stable - known open issue - which is why
+    udf_mlp.hip:mlp_variant keeps bf16x3 on the forward-mode kernel; this test pins that the default path is stable.)"""
+    net, state, cfg = mk("d8w256L10", prec)
+    gen = torch.Generator().manual_seed(5)
+    P = 131072
+    x = torch.rand(P, 3, generator=gen) * 2 - 1
+    du, dg = torch.randn(P, generator=gen) * 1e-3, torch.randn(P, 3, generator=gen) * 1e-4
+    ref = _hip_vjp(net, x, du, dg)
+    for _ in range(3):
+        out = _hip_vjp(net, x, du, dg)
+        assert all(torch.equal(out[k], ref[k]) for k in ref)
+    xb = (torch.rand(524288, 3, generator=gen) * 2 - 1).to(DEV)
+    u0, g0 = net.hip_udf(xb, with_grad=True)              # default variant for this mode and size
+    for _ in range(4):
+        u, g = net.hip_udf(xb, with_grad=True)
+        assert torch.equal(u, u0) and torch.equal(g, g0)
