@@ -32,7 +32,8 @@ class Embedder:
         _lib.require_cuda(inputs, "inputs")
         x = _lib.f32c(inputs.reshape(-1, 3))
         out = torch.empty(x.shape[0], self.out_dim, device=x.device, dtype=torch.float32)
-        _lib.check(_lib.lib().emap_embed(_lib.ptr(x), x.shape[0], self.num_freqs, _lib.ptr(out), _lib.stream_ptr()), "embed")
+        with _lib.on_device(x):
+            _lib.check(_lib.lib().emap_embed(_lib.ptr(x), x.shape[0], self.num_freqs, _lib.ptr(out), _lib.stream_ptr(x.device)), "embed")
         return out.reshape(*inputs.shape[:-1], self.out_dim)
 
 

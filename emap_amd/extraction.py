@@ -28,8 +28,9 @@ def null_direction(grads: torch.Tensor) -> torch.Tensor:
     g = _lib.f32c(grads)
     out = torch.empty(n, 3, device=g.device, dtype=torch.float32)
     if n:
-        _lib.check(_lib.lib().emap_null_direction(_lib.ptr(g), C.c_int64(n), k, _lib.ptr(out), _lib.stream_ptr()),
-                   "null_direction")
+        with _lib.on_device(g):
+            _lib.check(_lib.lib().emap_null_direction(_lib.ptr(g), C.c_int64(n), k, _lib.ptr(out), _lib.stream_ptr(g.device)),
+                       "null_direction")
     return out
 
 

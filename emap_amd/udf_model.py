@@ -130,7 +130,8 @@ class UDFNetwork(nn.Module):
         ga = (C.c_void_p * n)(*[t.data_ptr() for t in keep[0]])
         va = (C.c_void_p * n)(*[t.data_ptr() for t in keep[1]])
         ba = (C.c_void_p * n)(*[t.data_ptr() for t in keep[2]])
-        _lib.check(L.emap_pack_weights(C.byref(cfg), ga, va, ba, _lib.ptr(buf), prec, _lib.stream_ptr()), "pack_weights")
+        with _lib.on_device(buf):
+            _lib.check(L.emap_pack_weights(C.byref(cfg), ga, va, ba, _lib.ptr(buf), prec, _lib.stream_ptr(buf.device)), "pack_weights")
         self._pack_cache[prec] = (key, buf)
         return buf
 

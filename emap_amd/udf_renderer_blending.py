@@ -29,8 +29,9 @@ def sample_pdf(bins, weights, n_samples, det=False):
     b, w = _lib.f32c(bins), _lib.f32c(weights)
     N, n = b.shape
     out = torch.empty(N, n_samples, device=b.device, dtype=torch.float32)
-    _lib.check(_lib.lib().emap_sample_pdf(_lib.ptr(b), _lib.ptr(w), N, n, n_samples, _lib.ptr(out), None, None,
-                                          _lib.stream_ptr()), "sample_pdf")
+    with _lib.on_device(b):
+        _lib.check(_lib.lib().emap_sample_pdf(_lib.ptr(b), _lib.ptr(w), N, n, n_samples, _lib.ptr(out), None, None,
+                                              _lib.stream_ptr(b.device)), "sample_pdf")
     return out
 
 
