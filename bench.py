@@ -139,14 +139,10 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(state, kw, n_rays, mode):
-    """The oracle (CPU restatement pinned to the reference by tests/golden) on the same synthetic workload: all host cores
-    (BASELINE.md par. 3), 32 threads (eager torch on ~1e5-element ops stops scaling long before 256 threads and collapses when
-    oversubscribed - measured 5e2 ray-samples/s on 256 threads vs 4.5e4 on 32) and one thread.  `value` is the best of them,
-    `cores` says which.  Every configuration sizes its sample from a 32-ray probe so that the whole baseline stays near 30 s."""
+def _cpu_config(state, kw, n_rays, mode, threads, budget_s):
+    """One thread-count configuration of the CPU baseline (module level: the all-cores configuration runs it in a child process)."""
     from oracle import emap_oracle as O
     from emap_amd import synthetic
-    ncpu = os.cpu_count() or 1
     cfg = O.UDFConfig(d_in=3, d_out=1, d_hidden=kw["d_hidden"], n_layers=kw["n_layers"], skip_in=(4,), multires=kw["multires"])
     rcfg = O.RenderConfig(n_samples=64, n_importance=64, up_sample_steps=4)
     var, bp, gp = torch.tensor([0.3]), torch.tensor([0.5]), torch.tensor([0.3])
@@ -160,33 +156,53 @@ def cpu_baseline(state, kw, n_rays, mode):
                                                   edge_weight=1.0, igr_weight=0.1, igr_ns_weight=0.0)
         return lambda: O.render(state, cfg, rcfg, ro, rd, near, far, ds, var, bp, gp, cos_anneal_ratio=1.0, t_rand=tr, flip_saturation=0.9)
 
-    def config(threads, budget_s):
-        torch.set_num_threads(threads)
-        probe = make(32)
-        t0 = time.perf_counter(); probe(); t_probe = time.perf_counter() - t0
-        if t_probe > budget_s:                      # hopeless at this thread count: the probe is the sample
-            return {"threads": threads, "rays": 32, "runs": 1, "ms": t_probe * 1e3, "value": 32 * 128 / t_probe}
-        t0 = time.perf_counter(); probe(); t_probe = time.perf_counter() - t0
-        n = 32
-        while n * 2 <= n_rays and t_probe * (n * 2 / 32) <= budget_s / 3:
-            n *= 2
-        fn = make(n)
-        ts, t_end = [], time.time() + budget_s
-        while len(ts) < 1 or (time.time() < t_end and len(ts) < 5):
-            t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
-        ts.sort()
-        med = ts[len(ts) // 2]
-        return {"threads": threads, "rays": n, "runs": len(ts), "ms": med * 1e3, "value": n * 128 / med}
+    torch.set_num_threads(threads)
+    probe = make(32)
+    t0 = time.perf_counter(); probe(); t_probe = time.perf_counter() - t0
+    if t_probe > budget_s:                      # hopeless at this thread count: the probe is the sample
+        return {"threads": threads, "rays": 32, "runs": 1, "ms": t_probe * 1e3, "value": 32 * 128 / t_probe}
+    t0 = time.perf_counter(); probe(); t_probe = time.perf_counter() - t0
+    n = 32
+    while n * 2 <= n_rays and t_probe * (n * 2 / 32) <= budget_s / 3:
+        n *= 2
+    fn = make(n)
+    ts, t_end = [], time.time() + budget_s
+    while len(ts) < 1 or (time.time() < t_end and len(ts) < 5):
+        t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
+    ts.sort()
+    med = ts[len(ts) // 2]
+    return {"threads": threads, "rays": n, "runs": len(ts), "ms": med * 1e3, "value": n * 128 / med}
 
-    res = [config(t, b) for t, b in sorted({(min(32, ncpu), 10.0), (ncpu, 8.0), (1, 6.0)}, key=lambda x: -x[0])]
+
+def cpu_baseline(state, kw, n_rays, mode):
+    """The oracle (CPU restatement pinned to the reference by tests/golden) on the same synthetic workload: all host cores
+    (BASELINE.md par. 3), 32 threads (eager torch on ~1e5-element ops stops scaling long before 256 threads and collapses when
+    oversubscribed - measured 5e2 ray-samples/s on 256 threads vs 4.5e4 on 32) and one thread.  `value` is the best of them,
+    `cores` says which.  Every configuration sizes its sample from a 32-ray probe so that the whole baseline stays near 30 s."""
+    ncpu = os.cpu_count() or 1
+    config = lambda t, b: _cpu_config(state, kw, n_rays, mode, t, b)
+    res = [config(min(32, ncpu), 10.0), config(1, 6.0)]
+    if ncpu > 32:
+        # all host cores (BASELINE.md par. 3): eager torch on these ~1e5-element ops collapses when oversubscribed (measured on the
+        # 256-thread EPYC 9575F host: 50 s for 32 rays, 5e2 ray-samples/s), so that configuration runs in a child process with a
+        # deadline instead of holding the bench for minutes
+        code = ("import json,sys;sys.path.insert(0,%r);import bench,torch;from emap_amd import synthetic;"
+                "kw=%r;st=synthetic.make_udf_state(seed=42,pert=0.02,**kw);"
+                "print('CFG'+json.dumps(bench._cpu_config(st,kw,%d,%r,%d,8.0)))" % (ROOT, kw, n_rays, mode, ncpu))
+        try:
+            out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=25)
+            ln = [x for x in out.stdout.splitlines() if x.startswith("CFG")]
+            res.append(json.loads(ln[-1][3:]) if ln else {"threads": ncpu, "rays": 0, "runs": 0, "ms": None, "value": 0.0, "note": "failed"})
+        except subprocess.TimeoutExpired:
+            res.append({"threads": ncpu, "rays": 32, "runs": 0, "ms": None, "value": 0.0, "note": "no 32-ray run finished within 25 s"})
     torch.set_num_threads(min(32, ncpu))
     best = max(res, key=lambda c: c["value"])
     one = [c for c in res if c["threads"] == 1][0]
     what = "forward render()" if mode == "render" else "forward + loss.backward() (autograd double backward)"
     return {"value": best["value"], "unit": "ray-samples/s", "cores": best["threads"], "kind": "port", "cpu_model": cpu_model(),
             "host_cores": ncpu, "single_thread_value": one["value"],
-            "by_threads": {str(c["threads"]): {"value": c["value"], "rays": c["rays"], "runs": c["runs"], "ms_per_run": c["ms"]} for c in res},
-            "sample": f"{best['rays']} rays x 128 samples, {what}, median of {best['runs']} runs ({best['ms']:.0f} ms each) on "
+            "by_threads": {str(c["threads"]): {k: c[k] for k in c if k != "threads"} for c in res},
+            "sample": f"{best['rays']} rays x 128 samples, {what}, median of {best['runs']} runs ({best['ms'] or 0:.0f} ms each) on "
                       f"{best['threads']} threads (best of {sorted(c['threads'] for c in res)} threads); oracle/emap_oracle.py on torch CPU fp32"}
 
 
@@ -346,7 +362,7 @@ def main():
             # dominant kernel: the value+grad MLP launch over rays*S points; algorithmic work = value + reverse-mode input
             # gradient = 2F per point (SURVEY par. 8d)
             flops_launch = rays * S * 2 * F_POINT
-            rev = rays * S >= (10240 if a.precision == "f16x3" else 16384) and a.precision != "bf16x3"
+            rev = rays * S >= (10240 if a.precision in ("f16x3", "bf16x3") else 16384)
             dominant = (f"udf_mlp_rev_kernel<256,{a.precision}>" if rev else f"udf_mlp_fs2_kernel<256,{a.precision},4,grad>") + " (final value+grad pass)"
             alg = A_FWD
             metric = "ray-samples/sec (UDF MLP + composite)"

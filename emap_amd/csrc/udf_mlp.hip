@@ -304,11 +304,9 @@ static int mlp_variant(const NetLayout& L, int prec, int64_t P, bool grad) {
     const char* gm = getenv("EMAP_GRAD_MODE");
     const int grad_mode = !gm ? -1 : (!strcmp(gm, "fwd") ? 0 : (!strcmp(gm, "rev") ? 1 : -1));
     // reverse mode halves the MFMA work of a grad launch but a tile is two dependent sweeps: it wins once most CUs have a
-    // workgroup (measured crossover: f16x3 between 8k and 12k points, single-pass modes at 16k).  bf16x3 stays on the
-    // forward-mode kernel: its reverse instantiation is not run-to-run deterministic with two workgroups per CU (open issue,
-    // DESIGN.md par. 3.1).
+    // workgroup (measured crossover: the split modes between 8k and 12k points, single-pass modes at 16k).
     const int64_t rev_min = (prec == EMAP_PREC_F16X3 || prec == EMAP_PREC_BF16X3) ? 10240 : 16384;
-    if (grad && L.has_rev && forced < 0 && grad_mode != 0 && (prec != EMAP_PREC_BF16X3 || grad_mode == 1) && (P >= rev_min || grad_mode == 1)) return 3;
+    if (grad && L.has_rev && forced < 0 && grad_mode != 0 && (P >= rev_min || grad_mode == 1)) return 3;
     if (forced >= 0) return forced;
     (void)prec; (void)P;
     return 2;   // fs2 (two or three workgroups per CU) measured fastest or equal at every size and mode on MI355X

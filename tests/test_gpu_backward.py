@@ -378,9 +378,9 @@ def test_render_graph_replay_equals_eager_render():
 @pytest.mark.parametrize("prec", ["f16x3", "bf16x3", "f16", "bf16"])
 def test_large_launches_are_bit_stable_run_to_run(prec, monkeypatch):
     """Determinism stress (DESIGN.md par. 3.1): repeated launches of the big kernels on the same inputs are bit-identical -
-    the training backward (sweep + weight-gradient GEMMs + reduction) in all four modes, the reverse-sweep value+gradient kernel
-    in the three modes it is the default for.  (Its bf16x3 instantiation is NOT stable - known open issue - which is why
-    udf_mlp.hip:mlp_variant keeps bf16x3 on the forward-mode kernel; this test pins that the default path is stable.)"""
+    the training backward (sweep + weight-gradient GEMMs + reduction) and the reverse-sweep value+gradient kernel in all four
+    modes.  (Round 1's bf16x3 reverse kernel was neither stable nor right: all three split passes chained into ONE accumulator
+    set; with the cross terms in a second set - the f16x3 schedule - it is both, see udf_mlp_rev.inc.)"""
     net, state, cfg = mk("d8w256L10", prec)
     gen = torch.Generator().manual_seed(5)
     P = 131072
@@ -391,7 +391,11 @@ def test_large_launches_are_bit_stable_run_to_run(prec, monkeypatch):
         out = _hip_vjp(net, x, du, dg)
         assert all(torch.equal(out[k], ref[k]) for k in ref)
     xb = (torch.rand(524288, 3, generator=gen) * 2 - 1).to(DEV)
-    u0, g0 = net.hip_udf(xb, with_grad=True)              # default variant for this mode and size
-    for _ in range(4):
+    u0, g0 = net.hip_udf(xb, with_grad=True)              # reverse-sweep kernel (default at this size in every mode)
+    for _ in range(6):
         u, g = net.hip_udf(xb, with_grad=True)
         assert torch.equal(u, u0) and torch.equal(g, g0)
+    monkeypatch.setenv("EMAP_GRAD_MODE", "fwd")           # and it agrees with the forward-mode tangent kernel
+    uf, gf = net.hip_udf(xb[:65536], with_grad=True)
+    tol = {"f16x3": 5e-5, "bf16x3": 1e-4, "f16": 5e-3, "bf16": 5e-2}[prec]
+    assert rel(g0[:65536], gf) <= tol and rel(u0[:65536], uf) <= tol
