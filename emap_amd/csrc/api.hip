@@ -51,7 +51,7 @@ int launch_merge(const float*, const float*, const float*, const float*, int, in
 int launch_coarse(const float*, const float*, const float*, int, int, float*, float*, hipStream_t);
 int launch_composite(const float*, const float*, const float*, const float*, const float*, const float*, int, int,
                      const float*, float, float, float, float, int, float, float, float, float, int, const float*,
-                     const float*, const float*, float, const EmapCompositeOut*, float*, int32_t*, hipStream_t);
+                     const float*, const float*, float, const EmapCompositeOut*, float*, int32_t*, hipStream_t, unsigned* done = nullptr);
 int launch_embed(const float*, int64_t, int, float*, hipStream_t);
 void linspace_host(float, float, int, float*);
 int launch_sample_rays(const EmapRayDataset*, int, int, int, uint64_t, uint64_t, uint64_t*, const int64_t*, const EmapRayBatch*,
@@ -156,7 +156,7 @@ static int check_param_grads(const NetLayout& L, const EmapParamGrads* o, const 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Workspace {
-    size_t sample_dist, z_a, z_b, udf_a, udf_b, z_new, udf_new, partials, rev, total;
+    size_t sample_dist, z_a, z_b, udf_a, udf_b, z_new, z_new2, udf_new, partials, rev, total;
 };
 
 static Workspace plan_workspace(const EmapRenderParams& p, const NetLayout* L = nullptr) {
@@ -171,6 +171,7 @@ static Workspace plan_workspace(const EmapRenderParams& p, const NetLayout* L = 
     w.udf_a = off; off += align256(N * S * 4);
     w.udf_b = off; off += align256(N * S * 4);
     w.z_new = off; off += align256(N * (size_t)std::max(m, 1) * 4);
+    w.z_new2 = off; off += align256(N * (size_t)std::max(m, 1) * 4);
     w.udf_new = off; off += align256(N * (size_t)std::max(m, 1) * 4);
     w.partials = off; off += align256(N * 8 * 4);
     w.rev = off; off += L ? align256(rev_scratch_bytes(*L)) : 0;   // sigma' slabs of the reverse-mode value+gradient kernel
@@ -326,42 +327,55 @@ int emap_render_fwd(const EmapNetConfig* cfg, const void* packed, int prec, cons
     float* sample_dist = reinterpret_cast<float*>(ws + w.sample_dist);
     float* zbuf[2] = {reinterpret_cast<float*>(ws + w.z_a), reinterpret_cast<float*>(ws + w.z_b)};
     float* ubuf[2] = {reinterpret_cast<float*>(ws + w.udf_a), reinterpret_cast<float*>(ws + w.udf_b)};
-    float* z_new = reinterpret_cast<float*>(ws + w.z_new);
+    float* znew[2] = {reinterpret_cast<float*>(ws + w.z_new), reinterpret_cast<float*>(ws + w.z_new2)};
     float* udf_new = reinterpret_cast<float*>(ws + w.udf_new);
     float* partials = reinterpret_cast<float*>(ws + w.partials);
+    // ticket counter of the compositing kernel's last-block reduction: a word of the sample_dist slot, zeroed by the first
+    // sampler step of every render
+    unsigned* done = (steps > 0) ? reinterpret_cast<unsigned*>(ws + w.sample_dist + 64) : nullptr;
 
-    // coarse samples (render() :700-720); with no up-sampling they are the final z_vals
-    float* zc = (steps == 0) ? z_vals : zbuf[0];
-    rc = launch_coarse(near, far, t_rand, N, Sc, zc, sample_dist, st);
-    if (rc) return rc;
-
-    if (steps > 0) {
-        // importance_sample (:802-841)
+    if (steps == 0) {
+        // no up-sampling: the coarse samples (render() :700-720) are the final z_vals
+        rc = launch_coarse(near, far, t_rand, N, Sc, z_vals, sample_dist, st);
+        if (rc) return rc;
+    } else {
+        // importance_sample (:802-841) in 2*steps launches: the coarse z_vals are evaluated where they are consumed (the first
+        // MLP pass and the first sampler step, same separately rounded expression), every later sampler step merges the previous
+        // step's samples (cat_z_vals :355-377), up-samples (:228-353) and - in the last step - merges again, in one launch
         PointSource src;
         memset(&src, 0, sizeof(src));
-        src.rays_o = rays_o; src.rays_d = rays_d; src.z = zc; src.n_per_ray = Sc; src.mid = 0; src.sample_dist = sample_dist;
+        src.rays_o = rays_o; src.rays_d = rays_d; src.n_per_ray = Sc; src.mid = 0; src.sample_dist = sample_dist;
+        src.coarse = 1; src.near = near; src.far = far; src.t_rand = t_rand;
         rc = launch_mlp(L, packed, prec, src, (int64_t)N * Sc, ubuf[0], nullptr, st, err_flags);
         if (rc) return rc;
+        src.coarse = 0;
         int cur = 0, n = Sc;
         for (int i = 0; i < steps; ++i) {
             const bool last = (i + 1 == steps);
-            const float inv_s = 64.0f * (float)(1 << i);                       // :826
-            const float beta = 64.0f * (float)(1 << (i + 1));                  // :828
-            const float gamma = std::min(std::max(20.0f * (float)(1 << (K - i)), 20.0f), 320.0f);  // :830
-            rc = launch_upsample(rays_o, rays_d, zbuf[cur], ubuf[cur], N, n, m, sample_dist, inv_s, beta, gamma, z_new,
-                                 nullptr, err_flags, st);
+            StepArgs a;
+            memset(&a, 0, sizeof(a));
+            a.rays_o = rays_o; a.rays_d = rays_d; a.N = N; a.m = m; a.err = err_flags; a.sample_dist = sample_dist;
+            a.inv_s = 64.0f * (float)(1 << i);                                          // :826
+            a.beta = 64.0f * (float)(1 << (i + 1));                                     // :828
+            a.gamma = std::min(std::max(20.0f * (float)(1 << (K - i)), 20.0f), 320.0f);  // :830
+            a.z_new = znew[i & 1];
+            a.z_final = last ? z_vals : nullptr;
+            if (i == 0) {
+                a.n = Sc; a.udf = ubuf[0]; a.z_merged = zbuf[0]; a.near = near; a.far = far; a.t_rand = t_rand;
+                a.done_reset = done;
+            } else {
+                a.n = n; a.z = zbuf[cur]; a.udf = ubuf[cur]; a.z_prev = znew[(i - 1) & 1]; a.udf_prev = udf_new;
+                a.z_merged = zbuf[cur ^ 1]; a.udf_merged = ubuf[cur ^ 1];
+                cur ^= 1;
+                n += m;
+            }
+            rc = launch_sampler_step(i == 0, last, a, st);
             if (rc) return rc;
             if (!last) {
-                src.z = z_new; src.n_per_ray = m;
+                src.z = znew[i & 1]; src.n_per_ray = m;
                 rc = launch_mlp(L, packed, prec, src, (int64_t)N * m, udf_new, nullptr, st, err_flags);
                 if (rc) return rc;
-                rc = launch_merge(zbuf[cur], z_new, ubuf[cur], udf_new, N, n, m, zbuf[cur ^ 1], ubuf[cur ^ 1], nullptr, st);
-            } else {
-                rc = launch_merge(zbuf[cur], z_new, nullptr, nullptr, N, n, m, z_vals, nullptr, nullptr, st);
             }
-            if (rc) return rc;
-            cur ^= 1;
-            n += m;
         }
     }
 
@@ -377,7 +391,7 @@ int emap_render_fwd(const EmapNetConfig* cfg, const void* packed, int prec, cons
     return launch_composite(rays_o, rays_d, z_vals, udf, grad3, depth_scale, N, S, sample_dist, p->inv_s, p->beta, p->gamma,
                             p->cos_anneal_ratio, p->has_cos_anneal, p->flip_saturation, p->near_surface, p->sparse_scale,
                             p->background, p->has_background, p->variance_dev, p->beta_dev, p->gamma_dev, p->beta_min, out,
-                            partials, err_flags, st);
+                            partials, err_flags, st, done);
 }
 
 int emap_composite_bwd(const float* rays_o, const float* rays_d, const float* z, const float* udf, const float* grad3,

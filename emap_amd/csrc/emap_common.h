@@ -90,7 +90,30 @@ struct PointSource {
     int32_t n_per_ray;         // n
     int32_t mid;               // 1: evaluate at z + dists/2 with dists[last] = *sample_dist (render_core :435-449)
     const float* sample_dist;  // device scalar (mid=1)
+    // coarse=1: z is not read; z[ray][i] = near + (far-near)*linspace(0,1,n)[i] + t_rand*2/n is evaluated on the fly (render() :705-720)
+    const float* near;
+    const float* far;
+    const float* t_rand;       // may be null
+    int32_t coarse;
+    int32_t pad;
 };
+
+// one fused step of importance_sample (sampler.hip:sampler_step_kernel)
+struct StepArgs {
+    const float *rays_o, *rays_d;
+    const float *z, *udf;            // (N,n)  [coarse: z is not read]
+    const float *z_prev, *udf_prev;  // (N,m)  merge: the previous step's new samples and their udf
+    float *z_merged, *udf_merged;    // (N,n+m) merge outputs; coarse: z_merged (N,n) receives the coarse z_vals
+    const float *near, *far, *t_rand;   // coarse
+    float* sample_dist;              // read; coarse: written
+    float* z_new;                    // (N,m) this step's new samples
+    float* z_final;                  // (N,n'+m) tail
+    int N, n, m;
+    float inv_s, beta, gamma;
+    int32_t* err;
+    unsigned* done_reset;            // coarse: zeroed (the compositing kernel's ticket counter of this render)
+};
+int launch_sampler_step(bool coarse, bool tail, const StepArgs& a, hipStream_t st);
 
 // scratch: device buffer of at least rev_scratch_bytes(L) for the reverse-mode grad kernel (required when that kernel is
 // selected; mlp_uses_rev() tells)

@@ -163,64 +163,92 @@ __global__ __launch_bounds__(64) void sample_pdf_kernel(const float* bins, const
 // ---------------------------------------------------------------------------------------------
 // up_sample_unbias (udf_renderer_blending.py:228-353) -> z_new (N,m)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void upsample_kernel(const float* rays_o, const float* rays_d, const float* z,
-                                                      const float* udf, int N, int n, int m, const float* sample_dist,
-                                                      float inv_s, float beta, float gamma, float* z_new, int64_t* inds,
-                                                      int32_t* err) {
-    __shared__ float s_z[MAXS], s_u[MAXS], s_rad[MAXS], s_tc[MAXS], s_a[MAXS], s_b[MAXS], s_c[MAXS], s_d[MAXS + 1];
-    const int ray = blockIdx.x, lane = threadIdx.x;
-    const float ox = rays_o[3 * ray], oy = rays_o[3 * ray + 1], oz = rays_o[3 * ray + 2];
-    const float dx = rays_d[3 * ray], dy = rays_d[3 * ray + 1], dz = rays_d[3 * ray + 2];
-    const float sd = *sample_dist;
+struct UpsampleScratch { float rad[MAXS], tc[MAXS], a[MAXS], b[MAXS], c[MAXS], d[MAXS + 1]; };
+
+// the whole of up_sample_unbias on the LDS arrays s_z, s_u (n entries, filled and synchronised by the caller); the m new
+// samples go to samples_out (global or LDS), their searchsorted indices to inds_out (may be null)
+__device__ __forceinline__ void upsample_body(float ox, float oy, float oz, float dx, float dy, float dz, float sd, const float* s_z,
+                                              const float* s_u, UpsampleScratch& w, int n, int m, float inv_s, float beta, float gamma,
+                                              int lane, float* samples_out, int64_t* inds_out, int32_t* err) {
     for (int e = lane; e < n; e += 64) {
-        const float zz = z[(size_t)ray * n + e];
-        s_z[e] = zz;
-        s_u[e] = udf[(size_t)ray * n + e];
+        const float zz = s_z[e];
         const float px = FADD(ox, FMUL(dx, zz)), py = FADD(oy, FMUL(dy, zz)), pz = FADD(oz, FMUL(dz, zz));
-        s_rad[e] = sqrtf(FADD(FADD(FMUL(px, px), FMUL(py, py)), FMUL(pz, pz)));  // :249
+        w.rad[e] = sqrtf(FADD(FADD(FMUL(px, px), FMUL(py, py)), FMUL(pz, pz)));  // :249
     }
-    __syncthreads();
     // true_cos over intervals (:279) and vis_prob input over samples (:293-313)
     for (int e = lane; e < n - 1; e += 64)
-        s_tc[e] = FDIV(FSUB(s_u[e + 1], s_u[e]), FADD(FSUB(s_z[e + 1], s_z[e]), 1e-5f));
+        w.tc[e] = FDIV(FSUB(s_u[e + 1], s_u[e]), FADD(FSUB(s_z[e + 1], s_z[e]), 1e-5f));
     __syncthreads();
     for (int e = lane; e < n; e += 64) {
         const float dists_raw = (e < n - 1) ? FSUB(s_z[e + 1], s_z[e]) : sd;           // :254-263
-        const float vis_mask = (e == 0) ? 1.0f : ((s_tc[e - 1] < 0.05f) ? 1.0f : 0.0f);  // :293-300
+        const float vis_mask = (e == 0) ? 1.0f : ((w.tc[e - 1] < 0.05f) ? 1.0f : 0.0f);  // :293-300
         const float raw_occ = udf2logistic1(s_u[e], beta);                               // :303
         const float alpha_occ = FSUB(1.0f, expf(FMUL(FMUL(-relu_(raw_occ), gamma), dists_raw)));  // :305
-        s_a[e] = FADD(clipf(FADD(FSUB(1.0f, alpha_occ), vis_mask), 0.0f, 1.0f), 1e-7f);  // :312
+        w.a[e] = FADD(clipf(FADD(FSUB(1.0f, alpha_occ), vis_mask), 0.0f, 1.0f), 1e-7f);  // :312
     }
     __syncthreads();
-    wave_scan<true>(s_a, s_b, n, lane);  // vis_prob (:308-319)
+    wave_scan<true>(w.a, w.b, n, lane);  // vis_prob (:308-319)
     __syncthreads();
     for (int e = lane; e < n - 1; e += 64) {
-        const float cv = -fabsf(s_tc[e]);
-        const float pcv = (e == 0) ? 0.0f : -fabsf(s_tc[e - 1]);
-        const bool inside = (s_rad[e] < 1.0f) | (s_rad[e + 1] < 1.0f);                   // :250
+        const float cv = -fabsf(w.tc[e]);
+        const float pcv = (e == 0) ? 0.0f : -fabsf(w.tc[e - 1]);
+        const bool inside = (w.rad[e] < 1.0f) | (w.rad[e + 1] < 1.0f);                   // :250
         float cos_val = clipf(fminf(pcv, cv), -1e3f, 0.0f);                              // :284-290
         cos_val = inside ? cos_val : FMUL(cos_val, 0.0f);
         const float mid_udf = FMUL(FADD(s_u[e], s_u[e + 1]), 0.5f);
         const float dists = FSUB(s_z[e + 1], s_z[e]);
         const float ap = sdf2alpha(mid_udf, cos_val, dists, inv_s, false, 0.f);          // :327-330
         const float am = sdf2alpha(-mid_udf, cos_val, dists, inv_s, false, 0.f);
-        const float sp = s_b[e];
+        const float sp = w.b[e];
         const float alpha = FADD(FMUL(ap, sp), FMUL(am, FSUB(1.0f, sp)));               // :331
-        s_c[e] = alpha;
-        s_a[e] = FADD(FSUB(1.0f, alpha), 1e-7f);
+        w.c[e] = alpha;
+        w.a[e] = FADD(FSUB(1.0f, alpha), 1e-7f);
     }
     __syncthreads();
-    wave_scan<true>(s_a, s_b, n - 1, lane);  // transmittance (:334-343)
+    wave_scan<true>(w.a, w.b, n - 1, lane);  // transmittance (:334-343)
     __syncthreads();
-    for (int e = lane; e < n - 1; e += 64) s_c[e] = FMUL(s_c[e], s_b[e]);  // weights
+    for (int e = lane; e < n - 1; e += 64) w.c[e] = FMUL(w.c[e], w.b[e]);  // weights
     __syncthreads();
-    sample_pdf_wave(s_z, s_c, s_a, s_d, n, m, lane, z_new + (size_t)ray * m, inds ? inds + (size_t)ray * m : nullptr, err);
+    sample_pdf_wave(s_z, w.c, w.a, w.d, n, m, lane, samples_out, inds_out, err);
+}
+
+__global__ __launch_bounds__(64) void upsample_kernel(const float* rays_o, const float* rays_d, const float* z,
+                                                      const float* udf, int N, int n, int m, const float* sample_dist,
+                                                      float inv_s, float beta, float gamma, float* z_new, int64_t* inds,
+                                                      int32_t* err) {
+    __shared__ float s_z[MAXS], s_u[MAXS];
+    __shared__ UpsampleScratch w;
+    const int ray = blockIdx.x, lane = threadIdx.x;
+    const float ox = rays_o[3 * ray], oy = rays_o[3 * ray + 1], oz = rays_o[3 * ray + 2];
+    const float dx = rays_d[3 * ray], dy = rays_d[3 * ray + 1], dz = rays_d[3 * ray + 2];
+    const float sd = *sample_dist;
+    for (int e = lane; e < n; e += 64) {
+        s_z[e] = z[(size_t)ray * n + e];
+        s_u[e] = udf[(size_t)ray * n + e];
+    }
+    __syncthreads();
+    upsample_body(ox, oy, oz, dx, dy, dz, sd, s_z, s_u, w, n, m, inv_s, beta, gamma, lane, z_new + (size_t)ray * m,
+                  inds ? inds + (size_t)ray * m : nullptr, err);
 }
 
 // ---------------------------------------------------------------------------------------------
 // cat_z_vals: merge two sorted lists (stable: old samples first on ties), gather udf
 // (udf_renderer_blending.py:361-375)
 // ---------------------------------------------------------------------------------------------
+// stable rank-merge of the sorted LDS lists s_z[n] (old) and s_n[m] (new): element e of cat([old, new]) goes to rank(e)
+__device__ __forceinline__ int merge_rank(const float* s_z, const float* s_n, int n, int m, int e, float& v) {
+    if (e < n) {
+        v = s_z[e];
+        int lo = 0, hi = m;  // # new elements strictly less than v
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_n[mid] < v) lo = mid + 1; else hi = mid; }
+        return e + lo;
+    }
+    v = s_n[e - n];
+    int lo = 0, hi = n;  // # old elements <= v
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_z[mid] <= v) lo = mid + 1; else hi = mid; }
+    return (e - n) + lo;
+}
+
 __global__ __launch_bounds__(64) void merge_kernel(const float* z, const float* z_new, const float* udf,
                                                    const float* udf_new, int N, int n, int m, float* z_out,
                                                    float* udf_out, int64_t* perm) {
@@ -231,22 +259,77 @@ __global__ __launch_bounds__(64) void merge_kernel(const float* z, const float* 
     __syncthreads();
     const size_t ob = (size_t)ray * (n + m);
     for (int e = lane; e < n + m; e += 64) {
-        int rank;
         float v;
-        if (e < n) {
-            v = s_z[e];
-            int lo = 0, hi = m;  // # new elements strictly less than v
-            while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_n[mid] < v) lo = mid + 1; else hi = mid; }
-            rank = e + lo;
-        } else {
-            v = s_n[e - n];
-            int lo = 0, hi = n;  // # old elements <= v
-            while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_z[mid] <= v) lo = mid + 1; else hi = mid; }
-            rank = (e - n) + lo;
-        }
+        const int rank = merge_rank(s_z, s_n, n, m, e, v);
         z_out[ob + rank] = v;
         if (perm) perm[ob + rank] = e;
         if (udf_out) udf_out[ob + rank] = (e < n) ? udf[(size_t)ray * n + e] : udf_new[(size_t)ray * m + (e - n)];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// One step of importance_sample (udf_renderer_blending.py:824-839) as ONE launch per ray wave:
+//   [COARSE: the coarse z_vals of render() :705-720 computed in place (and sample_dist, :704)]
+//   [MERGE : cat_z_vals of the PREVIOUS step (:355-377): merge z/udf with the previous step's new samples]
+//   up_sample_unbias of this step (:228-353) on the merged lists, which never leave LDS
+//   [TAIL  : cat_z_vals(last=True) of this step: the final z_vals]
+// The kernels the C ABI exposes one by one (emap_upsample_step, emap_merge_sorted) share the bodies.
+// ---------------------------------------------------------------------------------------------
+
+template <bool COARSE, bool MERGE, bool TAIL>
+__global__ __launch_bounds__(64) void sampler_step_kernel(const StepArgs a) {
+    __shared__ float s_z[MAXS], s_u[MAXS], s_n[MAXS];
+    __shared__ UpsampleScratch w;
+    const int ray = blockIdx.x, lane = threadIdx.x;
+    const float ox = a.rays_o[3 * ray], oy = a.rays_o[3 * ray + 1], oz = a.rays_o[3 * ray + 2];
+    const float dx = a.rays_d[3 * ray], dy = a.rays_d[3 * ray + 1], dz = a.rays_d[3 * ray + 2];
+    int n = a.n;
+    const int m = a.m;
+    float sd;
+    if constexpr (COARSE) {
+        // sample_dist = ((far - near) / n_samples).mean() (:704): every wave forms the same fp64 sum in the same order
+        double sum = 0.0;
+        for (int r = lane; r < a.N; r += 64) sum += (double)FDIV(FSUB(a.far[r], a.near[r]), (float)n);
+        sd = (float)(wave_sum_d(sum) / (double)a.N);
+        if (ray == 0 && lane == 0) { *a.sample_dist = sd; if (a.done_reset) *a.done_reset = 0u; }
+        for (int e = lane; e < n; e += 64) {
+            const float lin = linspace_at(0.0f, 1.0f, n, e);
+            float v = FADD(a.near[ray], FMUL(FSUB(a.far[ray], a.near[ray]), lin));                   // :707
+            if (a.t_rand) v = FADD(v, FDIV(FMUL(a.t_rand[ray], 2.0f), (float)n));                    // :720
+            s_z[e] = v;
+            s_u[e] = a.udf[(size_t)ray * n + e];
+            a.z_merged[(size_t)ray * n + e] = v;
+        }
+    } else {
+        sd = *a.sample_dist;
+        if constexpr (MERGE) {
+            for (int e = lane; e < n; e += 64) w.a[e] = a.z[(size_t)ray * n + e];       // scratch as staging: old z
+            for (int e = lane; e < m; e += 64) s_n[e] = a.z_prev[(size_t)ray * m + e];
+            __syncthreads();
+            const size_t ob = (size_t)ray * (n + m);
+            for (int e = lane; e < n + m; e += 64) {
+                float v;
+                const int rank = merge_rank(w.a, s_n, n, m, e, v);
+                const float u = (e < n) ? a.udf[(size_t)ray * n + e] : a.udf_prev[(size_t)ray * m + (e - n)];
+                s_z[rank] = v; s_u[rank] = u;
+                a.z_merged[ob + rank] = v; a.udf_merged[ob + rank] = u;
+            }
+            n += m;
+        } else {
+            for (int e = lane; e < n; e += 64) { s_z[e] = a.z[(size_t)ray * n + e]; s_u[e] = a.udf[(size_t)ray * n + e]; }
+        }
+    }
+    __syncthreads();
+    upsample_body(ox, oy, oz, dx, dy, dz, sd, s_z, s_u, w, n, m, a.inv_s, a.beta, a.gamma, lane, s_n, nullptr, a.err);
+    __syncthreads();
+    for (int e = lane; e < m; e += 64) a.z_new[(size_t)ray * m + e] = s_n[e];
+    if constexpr (TAIL) {
+        const size_t ob = (size_t)ray * (n + m);
+        for (int e = lane; e < n + m; e += 64) {
+            float v;
+            const int rank = merge_rank(s_z, s_n, n, m, e, v);
+            a.z_final[ob + rank] = v;
+        }
     }
 }
 
@@ -288,7 +371,12 @@ struct CompositeArgs {
     float beta_min;
     EmapCompositeOut out;
     float* partials;
+    unsigned* done;        // optional: ticket counter (zero between launches); the last ray's wave then does the cross-ray reduction
+    int32_t* err;
 };
+
+__device__ void composite_reduce_body(const float* partials, int N, float* scalars, int32_t* err, const CompositeArgs& a, int tid, int nthreads,
+                                      double (*red)[5]);
 
 __global__ __launch_bounds__(64) void composite_kernel(const CompositeArgs a) {
     __shared__ float s_z[MAXS], s_tc[MAXS], s_a[MAXS], s_b[MAXS], s_al[MAXS], s_occ[MAXS];
@@ -385,25 +473,40 @@ __global__ __launch_bounds__(64) void composite_kernel(const CompositeArgs a) {
         float* p = a.partials + (size_t)ray * 8;
         p[0] = (float)e_rel; p[1] = (float)c_rel; p[2] = (float)e_ns; p[3] = (float)c_ns; p[4] = (float)sp;
     }
+    if (a.done && a.out.scalars) {
+        // last-block reduction (saves the separate composite_reduce launch inside emap_render_fwd): every wave publishes its
+        // partials, takes a ticket; the wave that draws the last one sums all rays in a FIXED order (deterministic)
+        __shared__ unsigned ticket;
+        __shared__ double red1[1][5];
+        __threadfence();
+        if (lane == 0) ticket = atomicAdd(a.done, 1u);
+        __syncthreads();
+        if (ticket == (unsigned)a.N - 1) {
+            __threadfence();
+            composite_reduce_body(a.partials, a.N, a.out.scalars, a.err, a, lane, 64, red1);
+            if (lane == 0) *a.done = 0u;
+        }
+    }
 }
 
 // deterministic cross-ray reduction of the eikonal terms (:618-625) and sparse_error (:642-644)
-__global__ __launch_bounds__(256) void composite_reduce_kernel(const float* partials, int N, float* scalars, int32_t* err,
-                                                               const CompositeArgs a) {
-    __shared__ double red[4][5];
+__device__ void composite_reduce_body(const float* partials, int N, float* scalars, int32_t* err, const CompositeArgs& a, int tid, int nthreads,
+                                      double (*red)[5]) {
+    const int nw = nthreads >> 6;
     double v[5] = {0, 0, 0, 0, 0};
-    for (int i = threadIdx.x; i < N; i += 256)
+    // partials may have been written by other workgroups of THIS launch (last-block mode): L1-bypassing loads
+    for (int i = tid; i < N; i += nthreads)
 #pragma unroll
-        for (int k = 0; k < 5; ++k) v[k] += (double)partials[(size_t)i * 8 + k];
+        for (int k = 0; k < 5; ++k) v[k] += (double)__hip_atomic_load(partials + (size_t)i * 8 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
     for (int k = 0; k < 5; ++k) v[k] = wave_sum_d(v[k]);
-    if ((threadIdx.x & 63) == 0)
+    if ((tid & 63) == 0)
 #pragma unroll
-        for (int k = 0; k < 5; ++k) red[threadIdx.x >> 6][k] = v[k];
+        for (int k = 0; k < 5; ++k) red[tid >> 6][k] = v[k];
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         double t[5];
-        for (int k = 0; k < 5; ++k) t[k] = red[0][k] + red[1][k] + red[2][k] + red[3][k];
+        for (int k = 0; k < 5; ++k) { t[k] = 0; for (int q = 0; q < nw; ++q) t[k] += red[q][k]; }
         const float e_rel = (float)t[0], c_rel = (float)t[1], e_ns = (float)t[2], c_ns = (float)t[3];
         const float ge = FDIV(e_rel, FADD(c_rel, 1e-5f));
         scalars[0] = ge;
@@ -420,6 +523,13 @@ __global__ __launch_bounds__(256) void composite_reduce_kernel(const float* part
         scalars[8] = FDIV(1.0f, inv_s_); scalars[9] = FDIV(1.0f, beta_); scalars[10] = gamma_; scalars[11] = inv_s_;
         if (err && ge != ge) atomicOr(err, EMAP_F_NAN_GRADERR);
     }
+}
+
+// deterministic cross-ray reduction of the eikonal terms (:618-625) and sparse_error (:642-644)
+__global__ __launch_bounds__(256) void composite_reduce_kernel(const float* partials, int N, float* scalars, int32_t* err,
+                                                               const CompositeArgs a) {
+    __shared__ double red[4][5];
+    composite_reduce_body(partials, N, scalars, err, a, threadIdx.x, 256, red);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -704,6 +814,20 @@ int launch_merge(const float* z, const float* z_new, const float* udf, const flo
     return check_launch("merge_sorted");
 }
 
+int launch_sampler_step(bool coarse, bool tail, const StepArgs& a, hipStream_t st) {
+    const int n_out = a.n + (coarse ? 0 : a.m);
+    if (a.n < 2 || n_out + a.m > MAXS || a.m < 1) { set_error("sampler_step: n=%d m=%d out of range (max %d)", a.n, a.m, MAXS); return EMAP_E_INVALID; }
+    if (a.N <= 0) return EMAP_OK;
+    if (coarse) {
+        if (tail) hipLaunchKernelGGL((sampler_step_kernel<true, false, true>), dim3(a.N), dim3(64), 0, st, a);
+        else hipLaunchKernelGGL((sampler_step_kernel<true, false, false>), dim3(a.N), dim3(64), 0, st, a);
+    } else {
+        if (tail) hipLaunchKernelGGL((sampler_step_kernel<false, true, true>), dim3(a.N), dim3(64), 0, st, a);
+        else hipLaunchKernelGGL((sampler_step_kernel<false, true, false>), dim3(a.N), dim3(64), 0, st, a);
+    }
+    return check_launch("sampler_step");
+}
+
 int launch_coarse(const float* near, const float* far, const float* t_rand, int N, int n_samples, float* z,
                   float* sample_dist, hipStream_t st) {
     if (N <= 0) return EMAP_OK;
@@ -717,7 +841,7 @@ int launch_composite(const float* rays_o, const float* rays_d, const float* z, c
                      const float* depth_scale, int N, int S, const float* sample_dist, float inv_s, float beta,
                      float gamma, float car, int anneal, float flip_sat, float near_surface, float sparse_scale,
                      float background, int has_bg, const float* var_p, const float* beta_p, const float* gamma_p,
-                     float beta_min, const EmapCompositeOut* out, float* partials, int32_t* err, hipStream_t st) {
+                     float beta_min, const EmapCompositeOut* out, float* partials, int32_t* err, hipStream_t st, unsigned* done) {
     if (S < 1 || S > MAXS) { set_error("composite: S=%d out of range (max %d)", S, MAXS); return EMAP_E_INVALID; }
     if (!out || !partials) { set_error("composite: out/partials must not be null"); return EMAP_E_INVALID; }
     if (N <= 0) return EMAP_OK;
@@ -727,9 +851,10 @@ int launch_composite(const float* rays_o, const float* rays_d, const float* z, c
     a.anneal = anneal; a.flip_sat = flip_sat; a.near_surface = near_surface; a.sparse_scale = sparse_scale;
     a.background = background; a.has_bg = has_bg; a.out = *out; a.partials = partials;
     a.var_p = var_p; a.beta_p = beta_p; a.gamma_p = gamma_p; a.beta_min = beta_min;
+    a.done = done; a.err = err;
     if (var_p && (!beta_p || !gamma_p)) { set_error("composite: variance_dev given without beta_dev/gamma_dev"); return EMAP_E_INVALID; }
     hipLaunchKernelGGL(composite_kernel, dim3(N), dim3(64), 0, st, a);
-    if (out->scalars) hipLaunchKernelGGL(composite_reduce_kernel, dim3(1), dim3(256), 0, st, partials, N, out->scalars, err, a);
+    if (out->scalars && !done) hipLaunchKernelGGL(composite_reduce_kernel, dim3(1), dim3(256), 0, st, partials, N, out->scalars, err, a);
     return check_launch("composite");
 }
 

@@ -622,7 +622,8 @@ def test_north_star_batch_properties(N, prec, tol):
         assert float(same.float().mean()) >= 0.8, float(same.float().mean())
         assert rel(o1["edge"][sl][same.to(DEV)], ref["edge"][same]) <= tol and rel(o1["depth"][sl][same.to(DEV)], ref["depth"][same]) <= tol
     # (a re-sampled ray can move by 10 % in depth when its weight sits in one or two samples; as a batch the rays agree)
-    assert float((o1["edge"][sl].cpu() - ref["edge"]).abs().mean()) <= 5e-3 and float((o1["depth"][sl].cpu() - ref["depth"]).abs().mean()) <= 2e-2
+    k = 1.0 if prec == "f16x3" else 10.0                     # single-pass bf16: a few per cent everywhere
+    assert float((o1["edge"][sl].cpu() - ref["edge"]).abs().mean()) <= 5e-3 * k and float((o1["depth"][sl].cpu() - ref["depth"]).abs().mean()) <= 2e-2 * k
 
 
 # ---------------------------------------------------------------------------------------- extraction queries (par. 8 f2)
