@@ -263,7 +263,9 @@ void build_vjp_layout(const NetLayout& L, VjpLayout* V) {
         }
         V->z_rt[l] = last ? 1 : 2 * L.layer[l].n_pairs; V->z_off[l] = z; z += V->z_rt[l] * 2;
     }
-    V->a_tile_kb = a; V->z_tile_kb = z; V->s_slab_kb = s;
+    V->a_tile_kb = a; V->z_tile_kb = z;
+    (void)s;
+    V->s_slab_kb = (L.n_lin - 1) * (L.H / 32) * 4;   // per workgroup: [hidden layer][tile pair][4 x 64 lanes x 16 B] lane-linear (a', sigma')
 }
 
 int launch_pack(const NetLayout& L, const float* const* g, const float* const* v, const float* const* b,
