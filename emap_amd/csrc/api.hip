@@ -51,7 +51,7 @@ int launch_merge(const float*, const float*, const float*, const float*, int, in
 int launch_coarse(const float*, const float*, const float*, int, int, float*, float*, hipStream_t);
 int launch_composite(const float*, const float*, const float*, const float*, const float*, const float*, int, int,
                      const float*, float, float, float, float, int, float, float, float, float, int, const float*,
-                     const float*, const float*, float, const EmapCompositeOut*, float*, int32_t*, hipStream_t, unsigned* done = nullptr);
+                     const float*, const float*, float, const EmapCompositeOut*, float*, int32_t*, hipStream_t);
 int launch_embed(const float*, int64_t, int, float*, hipStream_t);
 void linspace_host(float, float, int, float*);
 int launch_sample_rays(const EmapRayDataset*, int, int, int, uint64_t, uint64_t, uint64_t*, const int64_t*, const EmapRayBatch*,
@@ -330,9 +330,6 @@ int emap_render_fwd(const EmapNetConfig* cfg, const void* packed, int prec, cons
     float* znew[2] = {reinterpret_cast<float*>(ws + w.z_new), reinterpret_cast<float*>(ws + w.z_new2)};
     float* udf_new = reinterpret_cast<float*>(ws + w.udf_new);
     float* partials = reinterpret_cast<float*>(ws + w.partials);
-    // ticket counter of the compositing kernel's last-block reduction: a word of the sample_dist slot, zeroed by the first
-    // sampler step of every render
-    unsigned* done = (steps > 0) ? reinterpret_cast<unsigned*>(ws + w.sample_dist + 64) : nullptr;
 
     if (steps == 0) {
         // no up-sampling: the coarse samples (render() :700-720) are the final z_vals
@@ -362,7 +359,6 @@ int emap_render_fwd(const EmapNetConfig* cfg, const void* packed, int prec, cons
             a.z_final = last ? z_vals : nullptr;
             if (i == 0) {
                 a.n = Sc; a.udf = ubuf[0]; a.z_merged = zbuf[0]; a.near = near; a.far = far; a.t_rand = t_rand;
-                a.done_reset = done;
             } else {
                 a.n = n; a.z = zbuf[cur]; a.udf = ubuf[cur]; a.z_prev = znew[(i - 1) & 1]; a.udf_prev = udf_new;
                 a.z_merged = zbuf[cur ^ 1]; a.udf_merged = ubuf[cur ^ 1];
@@ -391,7 +387,7 @@ int emap_render_fwd(const EmapNetConfig* cfg, const void* packed, int prec, cons
     return launch_composite(rays_o, rays_d, z_vals, udf, grad3, depth_scale, N, S, sample_dist, p->inv_s, p->beta, p->gamma,
                             p->cos_anneal_ratio, p->has_cos_anneal, p->flip_saturation, p->near_surface, p->sparse_scale,
                             p->background, p->has_background, p->variance_dev, p->beta_dev, p->gamma_dev, p->beta_min, out,
-                            partials, err_flags, st, done);
+                            partials, err_flags, st);
 }
 
 int emap_composite_bwd(const float* rays_o, const float* rays_d, const float* z, const float* udf, const float* grad3,

@@ -111,7 +111,6 @@ struct StepArgs {
     int N, n, m;
     float inv_s, beta, gamma;
     int32_t* err;
-    unsigned* done_reset;            // coarse: zeroed (the compositing kernel's ticket counter of this render)
 };
 int launch_sampler_step(bool coarse, bool tail, const StepArgs& a, hipStream_t st);
 

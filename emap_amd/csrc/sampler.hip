@@ -291,7 +291,7 @@ __global__ __launch_bounds__(64) void sampler_step_kernel(const StepArgs a) {
         double sum = 0.0;
         for (int r = lane; r < a.N; r += 64) sum += (double)FDIV(FSUB(a.far[r], a.near[r]), (float)n);
         sd = (float)(wave_sum_d(sum) / (double)a.N);
-        if (ray == 0 && lane == 0) { *a.sample_dist = sd; if (a.done_reset) *a.done_reset = 0u; }
+        if (ray == 0 && lane == 0) *a.sample_dist = sd;
         for (int e = lane; e < n; e += 64) {
             const float lin = linspace_at(0.0f, 1.0f, n, e);
             float v = FADD(a.near[ray], FMUL(FSUB(a.far[ray], a.near[ray]), lin));                   // :707
@@ -371,8 +371,6 @@ struct CompositeArgs {
     float beta_min;
     EmapCompositeOut out;
     float* partials;
-    unsigned* done;        // optional: ticket counter (zero between launches); the last ray's wave then does the cross-ray reduction
-    int32_t* err;
 };
 
 __device__ void composite_reduce_body(const float* partials, int N, float* scalars, int32_t* err, const CompositeArgs& a, int tid, int nthreads,
@@ -473,20 +471,6 @@ __global__ __launch_bounds__(64) void composite_kernel(const CompositeArgs a) {
         float* p = a.partials + (size_t)ray * 8;
         p[0] = (float)e_rel; p[1] = (float)c_rel; p[2] = (float)e_ns; p[3] = (float)c_ns; p[4] = (float)sp;
     }
-    if (a.done && a.out.scalars) {
-        // last-block reduction (saves the separate composite_reduce launch inside emap_render_fwd): every wave publishes its
-        // partials, takes a ticket; the wave that draws the last one sums all rays in a FIXED order (deterministic)
-        __shared__ unsigned ticket;
-        __shared__ double red1[1][5];
-        __threadfence();
-        if (lane == 0) ticket = atomicAdd(a.done, 1u);
-        __syncthreads();
-        if (ticket == (unsigned)a.N - 1) {
-            __threadfence();
-            composite_reduce_body(a.partials, a.N, a.out.scalars, a.err, a, lane, 64, red1);
-            if (lane == 0) *a.done = 0u;
-        }
-    }
 }
 
 // deterministic cross-ray reduction of the eikonal terms (:618-625) and sparse_error (:642-644)
@@ -494,10 +478,12 @@ __device__ void composite_reduce_body(const float* partials, int N, float* scala
                                       double (*red)[5]) {
     const int nw = nthreads >> 6;
     double v[5] = {0, 0, 0, 0, 0};
-    // partials may have been written by other workgroups of THIS launch (last-block mode): L1-bypassing loads
-    for (int i = tid; i < N; i += nthreads)
-#pragma unroll
-        for (int k = 0; k < 5; ++k) v[k] += (double)__hip_atomic_load(partials + (size_t)i * 8 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    for (int i = tid; i < N; i += nthreads) {
+        const f4 lo = *reinterpret_cast<const f4*>(partials + (size_t)i * 8);
+        const float hi = partials[(size_t)i * 8 + 4];
+        v[0] += (double)lo[0]; v[1] += (double)lo[1]; v[2] += (double)lo[2]; v[3] += (double)lo[3]; v[4] += (double)hi;
+    }
 #pragma unroll
     for (int k = 0; k < 5; ++k) v[k] = wave_sum_d(v[k]);
     if ((tid & 63) == 0)
@@ -841,7 +827,7 @@ int launch_composite(const float* rays_o, const float* rays_d, const float* z, c
                      const float* depth_scale, int N, int S, const float* sample_dist, float inv_s, float beta,
                      float gamma, float car, int anneal, float flip_sat, float near_surface, float sparse_scale,
                      float background, int has_bg, const float* var_p, const float* beta_p, const float* gamma_p,
-                     float beta_min, const EmapCompositeOut* out, float* partials, int32_t* err, hipStream_t st, unsigned* done) {
+                     float beta_min, const EmapCompositeOut* out, float* partials, int32_t* err, hipStream_t st) {
     if (S < 1 || S > MAXS) { set_error("composite: S=%d out of range (max %d)", S, MAXS); return EMAP_E_INVALID; }
     if (!out || !partials) { set_error("composite: out/partials must not be null"); return EMAP_E_INVALID; }
     if (N <= 0) return EMAP_OK;
@@ -851,10 +837,9 @@ int launch_composite(const float* rays_o, const float* rays_d, const float* z, c
     a.anneal = anneal; a.flip_sat = flip_sat; a.near_surface = near_surface; a.sparse_scale = sparse_scale;
     a.background = background; a.has_bg = has_bg; a.out = *out; a.partials = partials;
     a.var_p = var_p; a.beta_p = beta_p; a.gamma_p = gamma_p; a.beta_min = beta_min;
-    a.done = done; a.err = err;
     if (var_p && (!beta_p || !gamma_p)) { set_error("composite: variance_dev given without beta_dev/gamma_dev"); return EMAP_E_INVALID; }
     hipLaunchKernelGGL(composite_kernel, dim3(N), dim3(64), 0, st, a);
-    if (out->scalars && !done) hipLaunchKernelGGL(composite_reduce_kernel, dim3(1), dim3(256), 0, st, partials, N, out->scalars, err, a);
+    if (out->scalars) hipLaunchKernelGGL(composite_reduce_kernel, dim3(1), dim3(256), 0, st, partials, N, out->scalars, err, a);
     return check_launch("composite");
 }
 

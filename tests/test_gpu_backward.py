@@ -399,3 +399,49 @@ def test_large_launches_are_bit_stable_run_to_run(prec, monkeypatch):
     uf, gf = net.hip_udf(xb[:65536], with_grad=True)
     tol = {"f16x3": 5e-5, "bf16x3": 1e-4, "f16": 5e-3, "bf16": 5e-2}[prec]
     assert rel(g0[:65536], gf) <= tol and rel(u0[:65536], uf) <= tol
+
+
+def test_training_trajectory_tracks_the_cpu_oracle():
+    """BASELINE config C5 in miniature (same init, same synthetic rays, build vs the CPU restatement that the goldens
+    pin to the reference): several optimizer steps of the native Trainer against the same steps taken with torch.autograd through
+    the oracle and torch.optim.Adam on the CPU - losses and parameters stay together."""
+    from emap_amd import synthetic
+    from emap_amd.parallel import Trainer
+    name, N, steps = "d4w128L10", 48, 6
+    net, state, cfg = mk(name, "f16x3")
+    r = mk_renderer(net, 32, 32, 4)
+    rays = synthetic.make_rays(N, seed=31)
+    te = synthetic.make_true_edge(N, seed=32)
+    tr = synthetic.make_t_rand(N, seed=33)
+    t = Trainer(r, lr_geo=2e-4, lr=1e-3, edge_weight=1.0, igr_weight=0.1, igr_ns_weight=0.05)
+    batch = dict(zip(("rays_o", "rays_d", "near", "far", "depth_scale"), [v.to(DEV) for v in rays]))
+    batch.update(cos_anneal_ratio=0.7, flip_saturation=0.5, t_rand=tr.to(DEV))
+    hip_losses = []
+    for _ in range(steps):
+        hip_losses.append(t.step(batch, te.to(DEV)).cpu())
+    r.check_errors()
+    # the same on the CPU: oracle + autograd + Adam with the reference's two parameter groups (runner_base.py:110-117)
+    st = {k: v.clone().requires_grad_(True) for k, v in state.items()}
+    var, bp, gp = [torch.tensor([v], requires_grad=True) for v in (0.3, 0.5, 0.3)]
+    opt = torch.optim.Adam([{"params": list(st.values()), "lr": 2e-4}, {"params": [var, bp, gp]}], lr=1e-3)
+    rcfg = O.RenderConfig(32, 32, 4)
+    cpu_losses = []
+    for _ in range(steps):
+        loss, edge_loss, g, extra, _ = O.loss_and_param_grads(st, cfg, rcfg, *rays, te, var, bp, gp, 0.7, 0.5, t_rand=tr.view(-1, 1),
+                                                              edge_weight=1.0, igr_weight=0.1, igr_ns_weight=0.05)
+        for k, p in st.items():
+            p.grad = g[k]
+        var.grad, bp.grad, gp.grad = extra["variance"], extra["beta"], extra["gamma"]
+        opt.step()
+        cpu_losses.append(torch.stack([loss, edge_loss]))
+    hl, cl = torch.stack(hip_losses), torch.stack(cpu_losses)
+    print("losses  HIP:", [f"{float(v):.6f}" for v in hl[:, 0]], " CPU oracle:", [f"{float(v):.6f}" for v in cl[:, 0]])
+    assert torch.allclose(hl, cl, rtol=5e-3), (hl, cl)
+    assert float(cl[-1, 0]) < float(cl[0, 0])                       # and it is actually descending
+    # Adam moves every entry by about lr per step whatever the size of its gradient, so entries whose gradient is fp32 noise go
+    # either way on either machine; the displacement of the parameter VECTOR is what must agree
+    dh = torch.cat([(p.detach().cpu() - state[k]).reshape(-1) for k, p in net.named_parameters()])
+    dc = torch.cat([(st[k].detach() - state[k]).reshape(-1) for k, _ in net.named_parameters()])
+    cos = float((dh * dc).sum() / (dh.norm() * dc.norm()))
+    print(f"parameter displacement after {steps} steps: cos(HIP, CPU oracle) = {cos:.5f}, |HIP|/|CPU| = {float(dh.norm() / dc.norm()):.4f}")
+    assert cos >= 0.98 and abs(float(dh.norm() / dc.norm()) - 1.0) <= 0.03
