@@ -12,6 +12,7 @@
 //                    skip concat, and applies the weight-norm VJP  W = g v/||v||  ->  dg, dv  (one wave per output row).
 //   absmax_kernel  : max|du|, max|dg| of a launch (the range scale K of the sweep).
 #include "emap_common.h"
+#include <stdlib.h>
 #include <string.h>
 #include <type_traits>
 #include <utility>
@@ -83,6 +84,38 @@ __device__ __forceinline__ void wg_static_for_impl(std::integer_sequence<int, Is
 template <int N, class F>
 __device__ __forceinline__ void wg_static_for(F&& f) { wg_static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f)); }
 
+template <int CT>
+__device__ __forceinline__ void wgrad_store(const WgradArgs& a, const WgradJob& J, int slice, int wave, int lane, f32x4 (&acc)[2][CT], float (&bsum)[2]) {
+    // partial block [slice][row tile 0..15][a_ct][64 lanes x 4]
+    float* pb = a.partial + J.part_off + (size_t)slice * 16 * J.a_ct * 256;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int rt = wave + 8 * i;
+        if (rt < J.z_rt) {
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                if (c < J.a_ct) {
+                    f32x4* dst = reinterpret_cast<f32x4*>(pb + ((size_t)rt * J.a_ct + c) * 256 + lane * 4);
+                    *dst = a.accumulate ? (*dst + acc[i][c]) : acc[i][c];
+                }
+            }
+        }
+    }
+    if (J.bias_off >= 0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float v = bsum[i];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            const int rt = wave + 8 * i;
+            if (rt < J.z_rt && lane < 16) {
+                float* dst = a.partial + J.bias_off + (size_t)slice * 256 + rt * 16 + lane;
+                *dst = a.accumulate ? (*dst + v) : v;
+            }
+        }
+    }
+}
+
 template <class V8, int NB>
 __device__ __forceinline__ void wgrad_run(const WgradArgs& a, const WgradJob& J, int slice, int wave, int lane) {
     constexpr int CT = 4 * NB;
@@ -149,38 +182,11 @@ __device__ __forceinline__ void wgrad_run(const WgradArgs& a, const WgradJob& J,
         for (; tile + 4 <= t1; tile += 4) block(std::integral_constant<int, 4>{}, tile);
         for (; tile < t1; ++tile) block(std::integral_constant<int, 1>{}, tile);
     }
-    // partial block [slice][row tile 0..15][a_ct][64 lanes x 4]
-    float* pb = a.partial + J.part_off + (size_t)slice * 16 * J.a_ct * 256;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int rt = wave + 8 * i;
-        if (rt < J.z_rt) {
-#pragma unroll
-            for (int c = 0; c < CT; ++c) {
-                if (c < J.a_ct) {
-                    f32x4* dst = reinterpret_cast<f32x4*>(pb + ((size_t)rt * J.a_ct + c) * 256 + lane * 4);
-                    *dst = a.accumulate ? (*dst + acc[i][c]) : acc[i][c];
-                }
-            }
-        }
-    }
-    if (J.bias_off >= 0) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            float v = bsum[i];
-            v += __shfl_xor(v, 16);
-            v += __shfl_xor(v, 32);
-            const int rt = wave + 8 * i;
-            if (rt < J.z_rt && lane < 16) {
-                float* dst = a.partial + J.bias_off + (size_t)slice * 256 + rt * 16 + lane;
-                *dst = a.accumulate ? (*dst + v) : v;
-            }
-        }
-    }
+    wgrad_store<CT>(a, J, slice, wave, lane, acc, bsum);
 }
 
 template <class V8>
-__global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgradArgs a) {
+__global__ __launch_bounds__(512, 1) void wgrad_direct_kernel(const WgradArgs a) {
     int ji = 0;
     while (ji + 1 < a.n_jobs && (int)blockIdx.x >= a.job[ji + 1].first_wg) ++ji;
     const WgradJob J = a.job[ji];
@@ -195,6 +201,102 @@ __global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgradArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// weight-gradient GEMM, operands staged through LDS by DMA (the default)
+// ---------------------------------------------------------------------------------------------
+// In wgrad_direct_kernel every one of the 8 waves pulls ALL column-tile fragments of a step (they share them; only the two Z
+// fragments are its own): 8 x 18 KiB per step through the CU's 64 B/clk vector-memory path = 2.3 k cycles against 1.0 k cycles
+// of MFMA per SIMD - L1-bandwidth bound by 2x, and every 1 KiB load costs its wave ~50 issue cycles.  Here each fragment of a
+// step is fetched ONCE per workgroup, straight into LDS (global_load_lds_dwordx4: lane-linear 1 KiB, exactly the fragment
+// layout), 2 A + 2 Z fragments per wave and step, and read back with ds_read_b128 (256 B/clk).  Ring of NST = D + 1 stages, D
+// steps in flight (no registers are involved, so nothing the compiler could copy: loads stay in flight across the loop
+// back-edge); per step: s_waitcnt vmcnt (my fragments of this step have landed) -> s_barrier (everyone's have, and everyone
+// has finished reading the stage about to be refilled) -> issue step u + D -> 18 ds_read_b128 + 32 MFMAs.
+__device__ __forceinline__ void wg_dma16(unsigned lds_dst, const char* gsrc) {
+    unsigned keep;   // M0 = LDS byte address of lane 0's 16 bytes; written in the statement that uses it (the compiler owns M0)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+template <class V8, int NB>
+__device__ __forceinline__ void wgrad_lds_run(const WgradArgs& a, const WgradJob& J, int slice, int wave, int lane, char* smem) {
+    constexpr int CT = 4 * NB;
+    constexpr int NA = (CT + 7) / 8;              // A fragments a wave fetches per step
+    constexpr int NLD = NA + 2;                   // DMA loads per wave and step
+    constexpr int D = 3, NST = D + 1;
+    constexpr int STAGE = (CT + 16) * 1024;       // A[CT] then Z[16 row tiles]
+    const int t0 = (int)(((long long)a.n_tiles * slice) / J.n_slices), t1 = (int)(((long long)a.n_tiles * (slice + 1)) / J.n_slices);
+    const int nsteps = 2 * (t1 - t0);
+    f32x4 acc[2][CT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum[2] = {0.f, 0.f};
+    if (nsteps > 0) {
+        const size_t zts = (size_t)a.z_tile_kb * 1024, ats = (size_t)a.a_tile_kb * 1024;
+        const char* zsrc = a.stash_z + (size_t)J.z_off * 1024 + lane * 16;
+        const char* asrc = a.stash_a + (size_t)J.a_off * 1024 + lane * 16;
+        const unsigned lds0 = (unsigned)(size_t)smem;
+        // what this wave fetches: A fragments 8i + wave (folded into the valid range: duplicates write identical bytes) and its Z rows
+        int ca[NA], zr[2];
+#pragma unroll
+        for (int i = 0; i < NA; ++i) ca[i] = 8 * i + ((8 * i + 8 <= CT) ? wave : wave % (CT - 8 * i));
+        zr[0] = wave < J.z_rt ? wave : J.z_rt - 1;
+        zr[1] = wave + 8 < J.z_rt ? wave + 8 : J.z_rt - 1;
+        auto issue = [&](int u) __attribute__((always_inline)) {
+            const int uu = u < nsteps ? u : nsteps - 1;          // past the end: a harmless re-fetch keeps the load count uniform
+            const int tile = t0 + (uu >> 1), sh = (uu & 1) * 1024;
+            const unsigned st = lds0 + (unsigned)(u % NST) * STAGE;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int cs = ca[i] < J.a_ct ? ca[i] : J.a_ct - 1;
+                wg_dma16(__builtin_amdgcn_readfirstlane(st + ca[i] * 1024), asrc + (size_t)tile * ats + cs * 2048 + sh);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                wg_dma16(__builtin_amdgcn_readfirstlane(st + (CT + zr[i]) * 1024), zsrc + (size_t)tile * zts + zr[i] * 2048 + sh);
+        };
+        for (int u = 0; u < D; ++u) issue(u);
+        for (int u = 0; u < nsteps; ++u) {
+            asm volatile("s_waitcnt vmcnt(%0)" :: "i"(NLD * (D - 1)) : "memory");
+            __builtin_amdgcn_s_barrier();
+            issue(u + D);
+            const char* st = smem + (size_t)(u % NST) * STAGE + lane * 16;
+            V8 z[2];
+            z[0] = *reinterpret_cast<const V8*>(st + (CT + zr[0]) * 1024);
+            z[1] = *reinterpret_cast<const V8*>(st + (CT + zr[1]) * 1024);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)   // value columns are K slots e with e % 4 < 2
+                bsum[i] += ((float)z[i][0] + (float)z[i][1]) + ((float)z[i][4] + (float)z[i][5]);
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                const V8 af = *reinterpret_cast<const V8*>(st + c * 1024);
+                acc[0][c] = mfma16w(z[0], af, acc[0][c]);
+                acc[1][c] = mfma16w(z[1], af, acc[1][c]);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tail re-fetches: no DMA may outlive the workgroup's LDS
+    }
+    wgrad_store<CT>(a, J, slice, wave, lane, acc, bsum);
+}
+
+template <class V8>
+__global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char wg_smem[];
+    int ji = 0;
+    while (ji + 1 < a.n_jobs && (int)blockIdx.x >= a.job[ji + 1].first_wg) ++ji;
+    const WgradJob J = a.job[ji];
+    const int slice = (int)blockIdx.x - J.first_wg;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nb = (J.a_ct + 3) >> 2;
+    if (nb <= 1) wgrad_lds_run<V8, 1>(a, J, slice, wave, lane, wg_smem);
+    else if (nb == 2) wgrad_lds_run<V8, 2>(a, J, slice, wave, lane, wg_smem);
+    else if (nb == 3) wgrad_lds_run<V8, 3>(a, J, slice, wave, lane, wg_smem);
+    else wgrad_lds_run<V8, 4>(a, J, slice, wave, lane, wg_smem);
+}
+
+// ---------------------------------------------------------------------------------------------
 // reduction over K-slices + un-permutation + weight-norm VJP
 // ---------------------------------------------------------------------------------------------
 struct ReduceArgs {
@@ -206,7 +308,7 @@ struct ReduceArgs {
     int32_t accumulate;         // 1: add to dg/dv/db instead of overwriting
     int32_t weight_norm;        // 0: dv = dW (g is ignored, dg untouched)
     int32_t n_lin, H, d0, multires, skip_l;
-    int32_t row_off[EMAP_MAX_LIN + 1];   // first global row of layer l (prefix sum of out_dim)
+    int32_t row_off[EMAP_MAX_LIN + 1];   // first 4-row group of layer l (prefix sum of ceil(out_dim / 4))
     int32_t out_dim[EMAP_MAX_LIN], in_prev[EMAP_MAX_LIN], has_pe[EMAP_MAX_LIN];
     int32_t job_h[EMAP_MAX_LIN], job_pe[EMAP_MAX_LIN];   // indices into job[] or -1
     WgradJob job[WGRAD_MAX_JOBS];
@@ -232,95 +334,134 @@ __device__ __forceinline__ float wave_sum_f(float v) {
     return v;
 }
 
-// element (row m of row tile rt, column n of column tile ct) of a job's summed partial
-__device__ __forceinline__ float partial_at(const float* partial, const WgradJob& J, int rt, int m, int ct, int n) {
-    const size_t e = ((size_t)rt * J.a_ct + ct) * 256 + ((m >> 2) * 16 + n) * 4 + (m & 3);
-    const size_t stride = (size_t)16 * J.a_ct * 256;
-    float s = 0.f;
-    for (int q = 0; q < J.n_slices; ++q) s += partial[J.part_off + q * stride + e];
-    return s;
-}
-
+// 4 consecutive output rows per wave: they are the 4 accumulator registers of one lane of the MFMA output, i.e. ONE 16-byte
+// word of the partial blocks per (column, slice) - every load is a float4 and a wave reads 256-byte runs.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const ReduceArgs a) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int grp = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    if (row >= a.row_off[a.n_lin]) return;
+    if (grp >= a.row_off[a.n_lin]) return;       // row_off counts groups of 4 rows here
     int l = 0;
-    while (row >= a.row_off[l + 1]) ++l;
-    const int o = row - a.row_off[l];
+    while (grp >= a.row_off[l + 1]) ++l;
+    const int o0 = 4 * (grp - a.row_off[l]);
+    const int out_dim = a.out_dim[l];
     const int in_prev = a.in_prev[l];
     const int n_in = in_prev + (a.has_pe[l] ? a.d0 : 0);
     const float inv_k = a.grad_scale / vjp_scale_from_w(a.absmax);
     const float mult = (l == a.skip_l) ? 0.70710678118654752440f : 1.0f;
-    const int rt = o >> 4, m = o & 15;
+    const int rt = o0 >> 4, mq = (o0 & 15) >> 2;
     // the last layer's Z level holds its single real row twice: row 0 = hi part, row 1 = lo part of the seeds (udf_mlp_vjp.inc)
     const bool last = (l == a.n_lin - 1);
     constexpr int MAXC = 6;     // ceil((256 + 63) / 64)
-    float dw[MAXC], vv[MAXC];
-    float dot = 0.f, nrm = 0.f;
-    const float* vrow = a.v[l] + (size_t)o * n_in;
+    float dw[4][MAXC], vv[4][MAXC];
+    float dot[4] = {0.f, 0.f, 0.f, 0.f}, nrm[4] = {0.f, 0.f, 0.f, 0.f};
+    // where this lane's columns live: one float4 per (column, slice); all columns' loads of a slice are issued together and the
+    // slice loop is unrolled, so ~20 independent 16-byte loads are in flight per lane (there are only ~2 waves per CU: the
+    // kernel is a latency chain, not a bandwidth problem)
+    const float* src[MAXC];
+    size_t str[MAXC];
+    int ns[MAXC];
+    int nmax = 0;
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
         const int k = lane + 64 * c;
-        dw[c] = 0.f; vv[c] = 0.f;
+        src[c] = a.partial; str[c] = 0; ns[c] = 0;
         if (k < n_in) {
-            float s;
-            if (k < in_prev) {
-                s = partial_at(a.partial, a.job[a.job_h[l]], rt, m, k >> 4, k & 15);
-                if (last) s += partial_at(a.partial, a.job[a.job_h[l]], rt, 1, k >> 4, k & 15);
-            } else {
+            int jb, ct, n;
+            if (k < in_prev) { jb = a.job_h[l]; ct = k >> 4; n = k & 15; }
+            else {
                 // natural PE column -> slot (sp, g, e) of the PE block (udf_mlp.hip:pack_kernel) -> row tile 2*sp + e/4, row 4g + e%4
                 const int pc = k - in_prev, M = a.multires;
                 int ang, kind;
                 if (pc < 3) { ang = (pc == 2) ? 3 * M + 1 : 3 * M; kind = (pc == 1) ? 1 : 0; }
                 else { const int q = pc - 3, kk = q / 6, r = q - 6 * kk; kind = r / 3; ang = 3 * kk + (r - 3 * kind); }
                 const int g = ang >> 3, qq = ang & 7, sp = qq >> 2, e = 2 * (qq & 3) + kind;
-                const int prow = 4 * g + (e & 3), ptile = 2 * sp + (e >> 2);
-                s = partial_at(a.partial, a.job[a.job_pe[l]], rt, m, ptile, prow);
-                if (last) s += partial_at(a.partial, a.job[a.job_pe[l]], rt, 1, ptile, prow);
+                jb = a.job_pe[l]; ct = 2 * sp + (e >> 2); n = 4 * g + (e & 3);
             }
-            dw[c] = s * inv_k * mult;      // d/dW_l of the reference's Linear (the packed weight holds W_l/sqrt2 for the skip layer)
-            vv[c] = vrow[k];
-            dot = fmaf(dw[c], vv[c], dot);
-            nrm = fmaf(vv[c], vv[c], nrm);
+            const WgradJob& J = a.job[jb];
+            src[c] = a.partial + J.part_off + (((size_t)rt * J.a_ct + ct) * 64 + mq * 16 + n) * 4;
+            str[c] = (size_t)16 * J.a_ct * 256;
+            ns[c] = J.n_slices;
+        }
+        nmax = max(nmax, ns[c]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) nmax = max(nmax, __shfl_xor(nmax, off));
+    f32x4 sum[MAXC];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) sum[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int q = 0; q < nmax; ++q) {           // fixed order per column: deterministic
+        f32x4 v[MAXC];
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)         // unconditional loads (a column with fewer slices re-reads its last one): they issue as one batch
+            v[c] = *reinterpret_cast<const f32x4*>(src[c] + (size_t)min(q, max(ns[c] - 1, 0)) * str[c]);
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            sum[c] += (q < ns[c]) ? v[c] : z;
         }
     }
-    dot = wave_sum_f(dot);
-    nrm = wave_sum_f(nrm);
-    if (last && a.weight_norm && a.g[l][o] != 0.f) {
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int k = lane + 64 * c;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { dw[r][c] = 0.f; vv[r][c] = 0.f; }
+        if (k < n_in) {
+            f32x4 sv = sum[c];
+            if (last) sv[0] += sv[1];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (o0 + r < out_dim) {
+                    dw[r][c] = sv[r] * inv_k * mult;      // d/dW_l of the reference's Linear (the packed weight holds W_l/sqrt2 for the skip layer)
+                    vv[r][c] = a.v[l][(size_t)(o0 + r) * n_in + k];
+                    dot[r] = fmaf(dw[r][c], vv[r][c], dot[r]);
+                    nrm[r] = fmaf(vv[r][c], vv[r][c], nrm[r]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { dot[r] = wave_sum_f(dot[r]); nrm[r] = wave_sum_f(nrm[r]); }
+    if (last && a.weight_norm && a.g[l][0] != 0.f) {
         // exact component of dW along W: dot(dW, v) = (||v||/g) sum_tiles ldot  (fixed order: deterministic)
         float ld = 0.f;
         for (int t = lane; t < a.n_tiles; t += 64) ld += a.ldot[t];
         ld = wave_sum_f(ld);
-        dot = ld * inv_k * sqrtf(nrm) / a.g[l][o];
+        dot[0] = ld * inv_k * sqrtf(nrm[0]) / a.g[l][0];
     }
-    float* dvrow = a.dv[l] + (size_t)o * n_in;
-    if (a.weight_norm) {
-        const float n = sqrtf(nrm), gg = a.g[l][o];
-        const float c1 = gg / n, c2 = dot / nrm;
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c) {
-            const int k = lane + 64 * c;
-            if (k < n_in) {
-                const float r = c1 * (dw[c] - c2 * vv[c]);
-                dvrow[k] = a.accumulate ? dvrow[k] + r : r;
+    for (int r = 0; r < 4; ++r) {
+        const int o = o0 + r;
+        if (o >= out_dim) break;
+        float* dvrow = a.dv[l] + (size_t)o * n_in;
+        if (a.weight_norm) {
+            const float n = sqrtf(nrm[r]), gg = a.g[l][o];
+            const float c1 = gg / n, c2 = dot[r] / nrm[r];
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) {
+                const int k = lane + 64 * c;
+                if (k < n_in) {
+                    const float x = c1 * (dw[r][c] - c2 * vv[r][c]);
+                    dvrow[k] = a.accumulate ? dvrow[k] + x : x;
+                }
+            }
+            if (lane == 0) { const float x = dot[r] / n; a.dg[l][o] = a.accumulate ? a.dg[l][o] + x : x; }
+        } else {
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) {
+                const int k = lane + 64 * c;
+                if (k < n_in) dvrow[k] = a.accumulate ? dvrow[k] + dw[r][c] : dw[r][c];
             }
         }
-        if (lane == 0) { const float r = dot / n; a.dg[l][o] = a.accumulate ? a.dg[l][o] + r : r; }
-    } else {
-#pragma unroll
-        for (int c = 0; c < MAXC; ++c) {
-            const int k = lane + 64 * c;
-            if (k < n_in) dvrow[k] = a.accumulate ? dvrow[k] + dw[c] : dw[c];
-        }
     }
-    if (lane == 0) {
+    if (lane < 4 && o0 + lane < out_dim) {
+        const int o = o0 + lane;
         const int jb = (a.job_h[l] >= 0) ? a.job_h[l] : a.job_pe[l];
         const WgradJob& J = a.job[jb];
         float s = 0.f;
         for (int q = 0; q < J.n_slices; ++q) s += a.partial[J.bias_off + (size_t)q * 256 + o] + (last ? a.partial[J.bias_off + (size_t)q * 256 + 1] : 0.f);
-        const float r = s * inv_k;
-        a.db[l][o] = a.accumulate ? a.db[l][o] + r : r;
+        const float x = s * inv_k;
+        a.db[l][o] = a.accumulate ? a.db[l][o] + x : x;
     }
 }
 
@@ -386,8 +527,23 @@ int launch_wgrad(const NetLayout& L, const VjpLayout& V, const WgradJob* jobs, i
     a.stash_a = stash_a; a.stash_z = stash_z; a.partial = partial;
     a.n_tiles = n_tiles; a.n_jobs = n_jobs; a.a_tile_kb = V.a_tile_kb; a.z_tile_kb = V.z_tile_kb; a.accumulate = accumulate;
     for (int i = 0; i < n_jobs; ++i) a.job[i] = jobs[i];
-    if (L.is_f16) hipLaunchKernelGGL(wgrad_kernel<f16x8>, dim3(total_wg), dim3(512), 0, st, a);
-    else hipLaunchKernelGGL(wgrad_kernel<bf16x8>, dim3(total_wg), dim3(512), 0, st, a);
+    const char* e = getenv("EMAP_WGRAD_LDS");   // 0: every wave loads its operands itself (A/B switch, read per call)
+    if (e && atoi(e) == 0) {
+        if (L.is_f16) hipLaunchKernelGGL(wgrad_direct_kernel<f16x8>, dim3(total_wg), dim3(512), 0, st, a);
+        else hipLaunchKernelGGL(wgrad_direct_kernel<bf16x8>, dim3(total_wg), dim3(512), 0, st, a);
+        return check_launch("wgrad");
+    }
+    constexpr size_t lds = 4 * 32 * 1024;        // NST stages of (16 A + 16 Z) KiB
+    static uint64_t attr_mask = 0;
+    if (attr_needed(attr_mask)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<f16x8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<bf16x8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+            return EMAP_E_LAUNCH;
+        }
+    }
+    if (L.is_f16) hipLaunchKernelGGL(wgrad_kernel<f16x8>, dim3(total_wg), dim3(512), lds, st, a);
+    else hipLaunchKernelGGL(wgrad_kernel<bf16x8>, dim3(total_wg), dim3(512), lds, st, a);
     return check_launch("wgrad");
 }
 
@@ -399,9 +555,9 @@ int launch_wgrad_reduce(const NetLayout& L, const WgradJob* jobs, int n_jobs, co
     memset(&a, 0, sizeof(a));
     a.partial = partial; a.absmax = absmax; a.ldot = ldot; a.n_tiles = n_tiles; a.grad_scale = grad_scale; a.accumulate = accumulate; a.weight_norm = weight_norm;
     a.n_lin = L.n_lin; a.H = L.H; a.d0 = L.d0; a.multires = L.multires; a.skip_l = L.skip_l;
-    int rows = 0;
+    int rows = 0;   // counted in groups of 4 rows (one wave each)
     for (int l = 0; l < L.n_lin; ++l) {
-        a.row_off[l] = rows; rows += L.layer[l].out_dim;
+        a.row_off[l] = rows; rows += (L.layer[l].out_dim + 3) / 4;
         a.out_dim[l] = L.layer[l].out_dim; a.in_prev[l] = L.layer[l].in_prev; a.has_pe[l] = L.layer[l].pe_ks ? 1 : 0;
         a.job_h[l] = job_h[l]; a.job_pe[l] = job_pe[l];
         a.g[l] = g ? g[l] : nullptr; a.v[l] = v[l]; a.dg[l] = dg ? dg[l] : nullptr; a.dv[l] = dv[l]; a.db[l] = db[l];
