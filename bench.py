@@ -49,6 +49,7 @@ MODE_DTYPE = {
     "bf16": "bf16 (single-pass bf16 MFMA, fp32 accumulate)",
 }
 MFMA_PEAK_TFLOPS = 2500.0  # dense f16/bf16 MFMA peak, MI355X_MICROARCH.md
+MFMA_MEASURED_TFLOPS = 2297.0   # scripts/probes/mfma_sustained.hip: v_mfma_f32_16x16x32_f16, two waves per SIMD, 140 ms sustained
 
 
 def parse():
@@ -385,7 +386,9 @@ def main():
                        "ranks": world, "devices": list(range(world))},
             "roofline": {"bound": "mfma", "kernel": dominant, "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / MFMA_PEAK_TFLOPS, "avg_launch_us": k_avg_s * 1e6, "launches": kn.value,
-                         "algorithmic_flops_per_launch": flops_launch, "traffic": None},
+                         "algorithmic_flops_per_launch": flops_launch, "traffic": None,
+                         # the sustained dense f16 rate measured on this hardware (profiles/r02_probe_mfma_sustained.txt), SURVEY par. 8d
+                         "peak_measured": MFMA_MEASURED_TFLOPS, "frac_of_measured_peak": ach / MFMA_MEASURED_TFLOPS},
             "whole_step_algorithmic_tflops": value * alg / 1e12,
             "whole_step_frac_of_mfma_peak": value * alg / 1e12 / MFMA_PEAK_TFLOPS / world,
         }
