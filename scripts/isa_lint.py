@@ -13,6 +13,13 @@ Model (straight-line, conservative): every asm `global_load` pushes its destinat
 operations are ignored, which only makes the hardware retire *more* than the model assumes).  The K-loops are straight-line
 code that ends with vmcnt(0), so the FIFO is empty at every loop back-edge and join.
 
+Second rule (write-after-read against the matrix pipe): an asm load may reuse a register that an MFMA issued just before it
+still reads as an operand (the compiler frees a fragment register after its last MFMA and the next prefetch lands in it).  The
+load's data cannot come back before the MFMA has read its sources (a vector-memory round trip is >= 100 cycles, the operand
+reads happen in the MFMA's first passes), but the rule is made explicit instead of being left to timing: such a load must be
+separated from that MFMA by >= 5 wait states.  Every asm load statement of the kernels opens with `s_nop 4` (needed anyway
+for the VALU-write-SGPR -> VMEM-address hazard), which satisfies it; the lint checks that no overwriting load comes closer.
+
 usage: isa_lint.py file.s [file.s ...]      exit status 1 on a violation
 """
 import re
@@ -22,6 +29,9 @@ RE_RANGE = re.compile(r"\bv\[(\d+):(\d+)\]")
 RE_SINGLE = re.compile(r"\bv(\d+)\b")
 RE_VMCNT = re.compile(r"s_waitcnt\b.*vmcnt\((\d+)\)")
 RE_LOAD = re.compile(r"^\s*global_load_dwordx4\s+v\[(\d+):(\d+)\]")
+RE_NOP = re.compile(r"^\s*s_nop\s+(\d+)")
+WAR_WINDOW = 2        # MFMAs this many instructions (or fewer) before an asm load are checked
+WAR_WAIT_STATES = 5   # required between such an MFMA and the load that overwrites one of its source registers
 
 
 def regs_of(text):
@@ -36,6 +46,8 @@ def regs_of(text):
 def lint(path):
     violations = []
     fifo = []          # list of (set(regs), line_no)
+    recent = []        # the last WAR_WINDOW non-asm instructions: (is_mfma, source registers, wait states it contributes)
+    nops = 0           # wait states accumulated inside the current asm statement before its load
     in_asm = False
     func = None
     n_loads = 0
@@ -47,6 +59,7 @@ def lint(path):
                 continue
             if s.startswith(";;#ASMSTART"):
                 in_asm = True
+                nops = 0
                 continue
             if s.startswith(";;#ASMEND"):
                 in_asm = False
@@ -70,9 +83,18 @@ def lint(path):
                 fifo = []                  # bare "s_waitcnt 0"-style encodings: everything retired
                 continue
             if in_asm:
+                mn = RE_NOP.match(s)
+                if mn:
+                    nops += int(mn.group(1)) + 1
                 m = RE_LOAD.match(s)
                 if m:
                     dst = set(range(int(m.group(1)), int(m.group(2)) + 1))
+                    between = nops
+                    for is_mfma, src, ws in reversed(recent):
+                        if is_mfma and (src & dst) and between < WAR_WAIT_STATES:
+                            violations.append((func, no, s + f"   <- overwrites an operand of an MFMA {between} wait states earlier", sorted(src & dst)))
+                        between += ws
+                    nops += 1
                     rest = s[m.end():]
                     busy = set().union(*[r for r, _ in fifo]) if fifo else set()
                     bad = (regs_of(rest) | dst) & busy
@@ -81,6 +103,14 @@ def lint(path):
                     fifo.append((dst, no))
                     n_loads += 1
                 continue
+            is_mfma = s.startswith("v_mfma")
+            mn = RE_NOP.match(s)
+            src = set()
+            if is_mfma:
+                ops = s.split(None, 1)[1].split(",") if len(s.split(None, 1)) > 1 else []
+                src = regs_of(",".join(ops[1:]))          # everything but the destination
+            recent.append((is_mfma, src, int(mn.group(1)) + 1 if mn else 1))
+            recent = recent[-WAR_WINDOW:]
             if not fifo:
                 continue
             busy = set().union(*[r for r, _ in fifo])

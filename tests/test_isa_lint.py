@@ -52,3 +52,18 @@ def test_compiler_waitcnt_also_retires(tmp_path):
     body = LOAD.format(a=10, b=13) + "\ts_waitcnt vmcnt(0) lgkmcnt(0)\n" + "\tv_add_f32_e32 v40, v10, v11\n"
     v, _ = run(tmp_path, body)
     assert v == []
+
+
+def test_load_that_overwrites_an_mfma_operand_needs_wait_states(tmp_path):
+    # write-after-read against the matrix pipe: a prefetch reusing the fragment register of the MFMA just issued must be
+    # >= 5 wait states behind it (the `s_nop 4` every asm load statement opens with); a bare load right behind it is flagged
+    mfma = "\tv_mfma_f32_16x16x32_f16 v[30:33], v[10:13], v[20:23], v[30:33]\n"
+    bare = "\t;;#ASMSTART\n\tglobal_load_dwordx4 v[10:13], v1, s[2:3]\n\t;;#ASMEND\n"
+    v, _ = run(tmp_path, mfma + bare + WAIT.format(n=0))
+    assert len(v) == 1 and v[0][3] == [10, 11, 12, 13]
+    v, _ = run(tmp_path, mfma + LOAD.format(a=10, b=13) + WAIT.format(n=0))          # with the s_nop 4: fine
+    assert v == []
+    v, _ = run(tmp_path, mfma + "\ts_nop 5\n" + bare + WAIT.format(n=0))              # wait states outside the statement count too
+    assert v == []
+    v, _ = run(tmp_path, mfma + bare.replace("v[10:13]", "v[40:43]") + WAIT.format(n=0))   # unrelated destination: fine
+    assert v == []
