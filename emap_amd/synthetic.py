@@ -154,3 +154,43 @@ def make_scene(n_images: int = 8, H: int = 100, W: int = 120, seed: int = 3, rad
     meta = {"scene_box": {"near": 0.05, "far": 6.0, "radius": 1.0, "aabb": [[-1, -1, -1], [1, 1, 1]]}, "height": H, "width": W,
             "frames": frames}
     return meta, edges
+
+
+def wireframe_segments(half: float = 0.45):
+    """The 12 edges of an axis-aligned cube of half-size `half` plus one face diagonal: (13, 2, 3) end points."""
+    c = np.array([[x, y, z] for x in (-half, half) for y in (-half, half) for z in (-half, half)], dtype=np.float64)
+    segs = [(c[i], c[j]) for i in range(8) for j in range(i + 1, 8) if np.sum(np.abs(c[i] - c[j]) > 1e-9) == 1]
+    segs.append((c[0], c[3]))
+    return np.array(segs)
+
+
+def make_wireframe_scene(n_images: int = 16, H: int = 200, W: int = 200, radius: float = 3.0, fov_deg: float = 30.0, half: float = 0.45):
+    """A MULTI-VIEW CONSISTENT synthetic dataset in the same wire format as make_scene: the edge maps are the anti-aliased
+    projections of one 3D wire frame (wireframe_segments) into cameras on a ring around it - something a UDF can actually fit,
+    for the convergence run of scripts/train_synthetic.py (BASELINE config C5 in miniature)."""
+    f = 0.5 * W / np.tan(np.deg2rad(fov_deg) / 2)
+    K = np.array([[f, 0, (W - 1) / 2, 0], [0, f, (H - 1) / 2, 0], [0, 0, 1, 0], [0, 0, 0, 1]], dtype=np.float64)
+    segs = wireframe_segments(half)
+    frames, edges = [], np.zeros((n_images, H, W, 1), dtype=np.float32)
+    ys, xs = np.mgrid[0:H, 0:W]
+    for i in range(n_images):
+        th, ph = 2 * np.pi * i / n_images + 0.2, 0.45 * np.sin(2.3 * i + 0.5)
+        c = radius * np.array([np.cos(th) * np.cos(ph), np.sin(ph), np.sin(th) * np.cos(ph)])
+        zax = -c / np.linalg.norm(c)
+        xax = np.cross([0.0, 1.0, 0.0], zax); xax /= np.linalg.norm(xax)
+        yax = np.cross(zax, xax)
+        c2w = np.eye(4); c2w[:3, 0], c2w[:3, 1], c2w[:3, 2], c2w[:3, 3] = xax, yax, zax, c
+        frames.append({"intrinsics": K.tolist(), "camtoworld": c2w.tolist(), "rgb_path": f"{i:04d}.png"})
+        R = c2w[:3, :3]
+        img = np.zeros((H, W))
+        for a, b in segs:
+            pa, pb = R.T @ (a - c), R.T @ (b - c)                     # camera coordinates (z forward)
+            x0, y0 = f * pa[0] / pa[2] + (W - 1) / 2, f * pa[1] / pa[2] + (H - 1) / 2
+            x1, y1 = f * pb[0] / pb[2] + (W - 1) / 2, f * pb[1] / pb[2] + (H - 1) / 2
+            t = np.clip(((xs - x0) * (x1 - x0) + (ys - y0) * (y1 - y0)) / ((x1 - x0) ** 2 + (y1 - y0) ** 2 + 1e-9), 0, 1)
+            d = np.hypot(xs - (x0 + t * (x1 - x0)), ys - (y0 + t * (y1 - y0)))
+            img = np.maximum(img, np.clip(1.5 - d, 0, 1))
+        edges[i, :, :, 0] = np.round(img * 255) / 255
+    meta = {"scene_box": {"near": 0.05, "far": 6.0, "radius": 1.0, "aabb": [[-1, -1, -1], [1, 1, 1]]}, "height": H, "width": W,
+            "frames": frames}
+    return meta, edges

@@ -448,3 +448,31 @@ def test_training_trajectory_tracks_the_cpu_oracle():
     cos = float((dh * dc).sum() / (dh.norm() * dc.norm()))
     print(f"parameter displacement after {steps} steps: cos(HIP, CPU oracle) = {cos:.5f}, |HIP|/|CPU| = {float(dh.norm() / dc.norm()):.4f}")
     assert cos >= 0.98 and abs(float(dh.norm() / dc.norm()) - 1.0) <= 0.03
+
+
+@pytest.mark.gpu
+def test_training_loop_fits_a_multi_view_consistent_wire_frame():
+    """BASELINE config C5 in miniature (scripts/train_synthetic.py runs the long version): device ray sampler -> render forward ->
+    HIP backward -> Adam on a synthetic wire frame whose edge maps are consistent across views; the edge loss must come down."""
+    from emap_amd import synthetic
+    from emap_amd.parallel import Trainer
+    torch.manual_seed(0)
+    kw = dict(NETS["d8w256L10"][0])
+    net = emap_amd.UDFNetwork(precision="f16x3", **kw).to(DEV)
+    r = mk_renderer(net, 64, 64, 4)
+    meta, edges = synthetic.make_wireframe_scene(n_images=8, H=100, W=100)
+    sampler = emap_amd.DeviceRaySampler.from_meta(meta, edges, device=DEV, seed=5)
+    sampler.set_image_perm(list(range(8)))
+    t = Trainer(r, lr_geo=1e-4, lr=5e-4, edge_weight=1.0, igr_weight=0.1, igr_ns_weight=0.0)
+    steps, losses = 400, []
+    for it in range(steps):
+        smp = sampler.gen_random_rays_patches_at(None, 256, importance_sample=True)
+        batch = {"rays_o": smp["rays"]["rays_o"], "rays_d": smp["rays"]["rays_v"], "near": 0.05, "far": 6.0,
+                 "depth_scale": smp["depth_scale"], "cos_anneal_ratio": min(1.0, it / 200), "flip_saturation": 0.0,
+                 "t_rand": torch.rand(256, 1, device=DEV) - 0.5}
+        losses.append(t.step(batch, smp["rays"]["edge"])[1])
+    r.check_errors()
+    el = torch.stack(losses).cpu()
+    first, last = float(el[:50].mean()), float(el[-50:].mean())
+    print(f"edge loss: first 50 steps {first:.4f}, last 50 steps {last:.4f}")
+    assert torch.isfinite(el).all() and last < 0.5 * first
