@@ -211,6 +211,12 @@ __global__ __launch_bounds__(512, 1) void wgrad_direct_kernel(const WgradArgs a)
 // steps in flight (no registers are involved, so nothing the compiler could copy: loads stay in flight across the loop
 // back-edge); per step: s_waitcnt vmcnt (my fragments of this step have landed) -> s_barrier (everyone's have, and everyone
 // has finished reading the stage about to be refilled) -> issue step u + D -> 18 ds_read_b128 + 32 MFMAs.
+#ifndef EMAP_WG_ABL
+#define EMAP_WG_ABL 0
+#endif
+#ifndef WGRAD_DEPTH
+#define WGRAD_DEPTH 3     // steps (32 KiB each) in flight per workgroup; the ring has WGRAD_DEPTH + 1 stages (<= 160 KiB of LDS)
+#endif
 __device__ __forceinline__ void wg_dma16(unsigned lds_dst, const char* gsrc) {
     unsigned keep;   // M0 = LDS byte address of lane 0's 16 bytes; written in the statement that uses it (the compiler owns M0)
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
@@ -222,7 +228,7 @@ __device__ __forceinline__ void wgrad_lds_run(const WgradArgs& a, const WgradJob
     constexpr int CT = 4 * NB;
     constexpr int NA = (CT + 7) / 8;              // A fragments a wave fetches per step
     constexpr int NLD = NA + 2;                   // DMA loads per wave and step
-    constexpr int D = 3, NST = D + 1;
+    constexpr int D = WGRAD_DEPTH, NST = D + 1;
     constexpr int STAGE = (CT + 16) * 1024;       // A[CT] then Z[16 row tiles]
     const int t0 = (int)(((long long)a.n_tiles * slice) / J.n_slices), t1 = (int)(((long long)a.n_tiles * (slice + 1)) / J.n_slices);
     const int nsteps = 2 * (t1 - t0);
@@ -233,9 +239,18 @@ __device__ __forceinline__ void wgrad_lds_run(const WgradArgs& a, const WgradJob
         for (int c = 0; c < CT; ++c) acc[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
     float bsum[2] = {0.f, 0.f};
     if (nsteps > 0) {
+#if EMAP_WG_ABL == 1
+        const size_t zts = (size_t)J.z_rt * 2048, ats = (size_t)J.a_ct * 2048;
+#else
         const size_t zts = (size_t)a.z_tile_kb * 1024, ats = (size_t)a.a_tile_kb * 1024;
+#endif
+#if EMAP_WG_ABL == 1   // timing ablation (wrong data): read as if the stash were level-major, each job streaming one contiguous range
+        const char* zsrc = a.stash_z + (size_t)J.z_off * 1024 * VJP_CHUNK_TILES + lane * 16;
+        const char* asrc = a.stash_a + (size_t)J.a_off * 1024 * VJP_CHUNK_TILES + lane * 16;
+#else
         const char* zsrc = a.stash_z + (size_t)J.z_off * 1024 + lane * 16;
         const char* asrc = a.stash_a + (size_t)J.a_off * 1024 + lane * 16;
+#endif
         const unsigned lds0 = (unsigned)(size_t)smem;
         // what this wave fetches: A fragments 8i + wave (folded into the valid range: duplicates write identical bytes) and its Z rows
         int ca[NA], zr[2];
@@ -533,7 +548,7 @@ int launch_wgrad(const NetLayout& L, const VjpLayout& V, const WgradJob* jobs, i
         else hipLaunchKernelGGL(wgrad_direct_kernel<bf16x8>, dim3(total_wg), dim3(512), 0, st, a);
         return check_launch("wgrad");
     }
-    constexpr size_t lds = 4 * 32 * 1024;        // NST stages of (16 A + 16 Z) KiB
+    constexpr size_t lds = (size_t)(WGRAD_DEPTH + 1) * 32 * 1024;   // NST stages of (16 A + 16 Z) KiB
     static uint64_t attr_mask = 0;
     if (attr_needed(attr_mask)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<f16x8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
