@@ -60,6 +60,10 @@ int launch_composite_bwd(const float*, const float*, const float*, const float*,
                          const float*, const EmapRenderParams*, const EmapCompositeGrads*, float*, float*, float*, uint32_t*,
                          hipStream_t);
 
+// ---- scalar tail of a training step (train.hip) ----
+int launch_train_stats(const float*, const float*, const float*, int, float, float*, float*, hipStream_t);
+int launch_train_loss(const float*, float, float, float, float*, hipStream_t);
+int launch_adam(float*, const float*, float*, float*, float*, int64_t, int64_t, float, float, float, float, float, hipStream_t);
 // ---- training backward (udf_mlp_vjp.inc, wgrad.hip) ----
 #define EMAP_VJP_DECL(m) \
     int launch_vjp_sweep_##m(const NetLayout&, const void*, const PointSource&, int64_t, int, int, const float*, const float*, \
@@ -494,6 +498,18 @@ int emap_render_bwd(const EmapNetConfig* cfg, const void* packed, int prec, cons
 int emap_sample_rays(const EmapRayDataset* ds, int img_idx, int batch, int importance, uint64_t seed, uint64_t offset,
                      uint64_t* counter_dev, const int64_t* pixels_in, const EmapRayBatch* out, void* stream) {
     return launch_sample_rays(ds, img_idx, batch, importance, seed, offset, counter_dev, pixels_in, out, static_cast<hipStream_t>(stream));
+}
+
+int emap_train_stats(const float* edge, const float* true_edge, const float* scalars, int N, float d_scale, float* d_edge,
+                     float* stats5, void* stream) {
+    return launch_train_stats(edge, true_edge, scalars, N, d_scale, d_edge, stats5, static_cast<hipStream_t>(stream));
+}
+int emap_train_loss(const float* stats5, float w_over_n, float igr_weight, float igr_ns_weight, float* out2, void* stream) {
+    return launch_train_loss(stats5, w_over_n, igr_weight, igr_ns_weight, out2, static_cast<hipStream_t>(stream));
+}
+int emap_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* step_dev, int64_t n, int64_t n_geo,
+                   float lr_geo, float lr, float beta1, float beta2, float eps, void* stream) {
+    return launch_adam(params, grads, exp_avg, exp_avg_sq, step_dev, n, n_geo, lr_geo, lr, beta1, beta2, eps, static_cast<hipStream_t>(stream));
 }
 
 int emap_null_direction(const float* grads, int64_t n, int k, float* dir, void* stream) {

@@ -1,0 +1,78 @@
+// train.hip - the scalar tail of a training step (SURVEY.md par. 8 a15): what runner_udf.py:124-168 does between render() and
+// loss.backward() and after it, as three small kernels instead of ~25 torch element-wise launches (each ~4.7 us of launch
+// latency on a 512-ray step) and a multi-tensor Adam that runs two 463 k-element tensors on 8 workgroups (2 x 25 us):
+//   train_stats_kernel : EdgeLoss (loss.py:14-17, mse) numerator and dL/d(edge) of the rank's rays + the eikonal sums render()
+//                        left in `scalars` -> the 5 numbers a data-parallel step exchanges
+//   train_loss_kernel  : loss = edge_loss * edge_weight + igr_weight * ge + igr_ns_weight * ge_ns   (runner_udf.py:155-159) from
+//                        the (global) statistics
+//   adam_kernel        : torch.optim.Adam with the reference's two parameter groups (runner_base.py:110-117) on the flat
+//                        parameter / gradient buffers; the step counter is a device word (graph-capturable)
+#include "emap_common.h"
+
+namespace emap {
+
+__global__ __launch_bounds__(256) void train_stats_kernel(const float* edge, const float* true_edge, const float* scalars, int N,
+                                                          float d_scale, float* d_edge, float* stats) {
+    __shared__ double red[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < N; i += 256) {
+        const float d = edge[i] - true_edge[i];
+        if (d_edge) d_edge[i] = d * d_scale;
+        s += (double)d * (double)d;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // scalars[3..6] = sum(relax*err), sum(relax), sum(near*err), sum(near)   (emap_composite_fwd)
+        stats[0] = scalars[4]; stats[1] = scalars[6]; stats[2] = scalars[3]; stats[3] = scalars[5];
+        stats[4] = (float)(red[0] + red[1] + red[2] + red[3]);
+    }
+}
+
+__global__ void train_loss_kernel(const float* stats, float w_over_n, float igr, float igr_ns, float* out) {
+    const float edge_loss = stats[4] * w_over_n;
+    out[0] = edge_loss + igr * stats[2] / (stats[0] + 1e-5f) + igr_ns * stats[3] / (stats[1] + 1e-5f);
+    out[1] = edge_loss;
+}
+
+// torch.optim.Adam (amsgrad=False, weight_decay=0, maximize=False), the arithmetic of torch's fused kernel:
+//   m = lerp(m, g, 1-b1);  v = b2 v + (1-b2) g^2;  p -= (lr / (1-b1^t)) * m / (sqrt(v) / sqrt(1-b2^t) + eps)
+__global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, float* step, long long n, long long n_geo,
+                                                   float lr_geo, float lr, float b1, float b2, float eps) {
+    const float t = *step + 1.0f;
+    const float bc1 = 1.0f - powf(b1, t), bc2s = sqrtf(1.0f - powf(b2, t));
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float gi = g[i];
+        const float mi = m[i] + (gi - m[i]) * (1.0f - b1);
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        const float step_size = ((i < n_geo) ? lr_geo : lr) / bc1;
+        p[i] -= step_size * mi / (sqrtf(vi) / bc2s + eps);
+    }
+}
+__global__ void adam_bump_kernel(float* step) { *step += 1.0f; }
+
+int launch_train_stats(const float* edge, const float* true_edge, const float* scalars, int N, float d_scale, float* d_edge, float* stats,
+                       hipStream_t st) {
+    if (!edge || !true_edge || !scalars || !stats || N < 0) { set_error("train_stats: null pointer"); return EMAP_E_INVALID; }
+    hipLaunchKernelGGL(train_stats_kernel, dim3(1), dim3(256), 0, st, edge, true_edge, scalars, N, d_scale, d_edge, stats);
+    return check_launch("train_stats");
+}
+int launch_train_loss(const float* stats, float w_over_n, float igr, float igr_ns, float* out, hipStream_t st) {
+    if (!stats || !out) { set_error("train_loss: null pointer"); return EMAP_E_INVALID; }
+    hipLaunchKernelGGL(train_loss_kernel, dim3(1), dim3(1), 0, st, stats, w_over_n, igr, igr_ns, out);
+    return check_launch("train_loss");
+}
+int launch_adam(float* p, const float* g, float* m, float* v, float* step, int64_t n, int64_t n_geo, float lr_geo, float lr, float b1,
+                float b2, float eps, hipStream_t st) {
+    if (!p || !g || !m || !v || !step || n < 0 || n_geo < 0 || n_geo > n) { set_error("adam_step: bad arguments"); return EMAP_E_INVALID; }
+    if (n == 0) return EMAP_OK;
+    const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, st, p, g, m, v, step, (long long)n, (long long)n_geo, lr_geo, lr, b1, b2, eps);
+    hipLaunchKernelGGL(adam_bump_kernel, dim3(1), dim3(1), 0, st, step);
+    return check_launch("adam_step");
+}
+
+}  // namespace emap

@@ -13,7 +13,10 @@ ge_ns + igr_weight * ge, zero_grad / backward / step).
   backward    emap_render_bwd writes dL/dtheta of the rank's share of the GLOBAL loss straight into one flat fp32 buffer laid
               out in parameters() order - the parameters themselves are views of one flat buffer as well
   all-reduce  ONE collective over that buffer (about 1.85 MB for d8 w256; the stats ride in its tail)
-  Adam        one fused update per parameter group on the flat buffers (torch.optim.Adam, the reference's optimizer)
+  Adam        one launch over the flat buffers (emap_adam_step: torch.optim.Adam's arithmetic with the reference's two parameter
+              groups, runner_base.py:110-117); on the CPU (tests) torch.optim.Adam itself
+The statistics, dL/d(edge) and the loss scalars are one small kernel each on the GPU (emap_train_stats / emap_train_loss) instead
+of ~25 element-wise torch launches - at 2 ms per step their launch latencies were 7 % of it.
 
 The eikonal terms are masked means over ALL rays of the batch (udf_renderer_blending.py:618-625): their denominators must be
 the global mask sums for the step to equal the single-GPU step.  ``eikonal_sync="exact"`` (default) therefore all-reduces the 5
@@ -71,13 +74,30 @@ class FlatParams:
         return s, e
 
 
+class _AdamGroups:
+    """What the step reads from `Trainer.optimizer` when the update runs in emap_adam_step: the two parameter groups of the
+    reference (runner_base.py:110-117) with the keys its schedulers touch (`g["lr"] = ...`, runner_base.py:140-141,159-160)."""
+
+    def __init__(self, trainer, lr_geo, lr, betas=(0.9, 0.999), eps=1e-8):
+        self._t = trainer
+        self.param_groups = [{"params": [trainer.p_geo], "lr": lr_geo, "betas": betas, "eps": eps},
+                             {"params": [trainer.p_sc], "lr": lr, "betas": betas, "eps": eps}]
+
+    def zero_grad(self, set_to_none: bool = False):       # the backward overwrites the flat gradient buffer
+        pass
+
+    def step(self):
+        self._t._native_adam()
+
+
 class Trainer:
     """Native data-parallel training step of the render hot path (see the module docstring)."""
 
     N_STATS = 8
 
     def __init__(self, renderer, lr_geo: float = 1e-4, lr: float = 5e-4, edge_weight: float = 1.0, igr_weight: float = 0.1,
-                 igr_ns_weight: float = 0.0, group=None, eikonal_sync: str = "exact", fused_adam: Optional[bool] = None):
+                 igr_ns_weight: float = 0.0, group=None, eikonal_sync: str = "exact", fused_adam: Optional[bool] = None,
+                 native_tail: Optional[bool] = None):
         assert eikonal_sync in ("exact", "local")
         self.r = renderer
         self.group = group
@@ -100,9 +120,23 @@ class Trainer:
         dev = self.flat.data.device
         if fused_adam is None:
             fused_adam = dev.type == "cuda"
-        # capturable: the step counters live on the device, so a whole step can be captured in a hipGraph (capture())
-        self.optimizer = torch.optim.Adam([{"params": [self.p_geo], "lr": lr_geo}, {"params": [self.p_sc]}], lr=lr,
-                                          **({"fused": True, "capturable": True} if fused_adam else {}))
+        # native tail (GPU default): statistics / loss scalars / Adam as three small HIP kernels (csrc/train.hip)
+        import os
+        if native_tail is None:      # EMAP_NATIVE_TAIL=0: torch element-wise ops + torch.optim.Adam (A/B switch)
+            native_tail = dev.type == "cuda" and os.environ.get("EMAP_NATIVE_TAIL", "1") != "0"
+        self.native_tail = bool(native_tail)
+        if self.native_tail:
+            assert g0 == 0 and s0 == g1 and s1 == self.flat.numel, "flat layout: geometry parameters first, then the scalars"
+            self._n_geo = g1
+            self._m = torch.zeros(self.flat.numel, device=dev)
+            self._v = torch.zeros(self.flat.numel, device=dev)
+            self._adam_t = torch.zeros(1, device=dev)          # step counter on the device: the update is graph-capturable
+            self._stats = torch.zeros(5, device=dev)
+            self.optimizer = _AdamGroups(self, lr_geo, lr)
+        else:
+            # capturable: the step counters live on the device, so a whole step can be captured in a hipGraph (capture())
+            self.optimizer = torch.optim.Adam([{"params": [self.p_geo], "lr": lr_geo}, {"params": [self.p_sc]}], lr=lr,
+                                              **({"fused": True, "capturable": True} if fused_adam else {}))
         self.collectives_per_step = 0 if _world(group) == 1 else (2 if eikonal_sync == "exact" else 1)
         # "local": every rank normalises by its own mask sums, so the sum over ranks needs the 1/world of a mean of means
         k = 1.0 / _world(group) if eikonal_sync == "local" else 1.0
@@ -123,9 +157,58 @@ class Trainer:
         self.r.backward_into(call, v, d_edge, None, self._igr, self._igr_ns if self.igr_ns_weight != 0.0 else None,
                              flat=flat_grad, scalars=scalars_glob)
 
+    def _native_adam(self):
+        from . import _lib
+        g0, g1 = self.optimizer.param_groups
+        dev = self.flat.data.device
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().emap_adam_step(_lib.ptr(self.flat.data), _lib.ptr(self.flat.grad), _lib.ptr(self._m), _lib.ptr(self._v),
+                                                 _lib.ptr(self._adam_t), self.flat.numel, self._n_geo, float(g0["lr"]), float(g1["lr"]),
+                                                 float(g0["betas"][0]), float(g0["betas"][1]), float(g0["eps"]), _lib.stream_ptr(dev)),
+                       "adam_step")
+
+    def _step_native(self, rays: Dict, true_edge: torch.Tensor, n_rays_global: Optional[int]):
+        from . import _lib
+        L = _lib.lib()
+        world = _world(self.group)
+        call, v, edge, scalars = self._forward(rays)
+        dev = edge.device
+        n_local = edge.numel()
+        n_glob = n_rays_global if n_rays_global is not None else n_local * world
+        te = true_edge.reshape(-1).to(torch.float32).contiguous()
+        assert te.numel() == n_local
+        d_edge = torch.empty(n_local, device=dev)
+        stats = self._stats
+        with torch.cuda.device(dev):
+            st = _lib.stream_ptr(dev)
+            _lib.check(L.emap_train_stats(_lib.ptr(edge), _lib.ptr(te), _lib.ptr(scalars), n_local, 2.0 * self.edge_weight / n_glob,
+                                          _lib.ptr(d_edge), _lib.ptr(stats), st), "train_stats")
+            sc_glob = scalars
+            if world > 1 and self.eikonal_sync == "exact":
+                dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=self.group)
+                sc_glob = scalars.clone()
+                sc_glob[4], sc_glob[6] = stats[0], stats[1]
+            g = self.flat.grad
+            self._backward(call, v, d_edge, sc_glob, g[:self.flat.numel])
+            if world > 1:
+                if self.eikonal_sync == "local":
+                    g[self.flat.numel:self.flat.numel + 5] = stats      # the statistics ride in the bucket's tail
+                dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+                if self.eikonal_sync == "local":
+                    stats = g[self.flat.numel:self.flat.numel + 5]
+            self.optimizer.step()
+            self.r.udf_network.invalidate_packed()   # the flat update does not bump the per-parameter version counters
+            out = torch.empty(2, device=dev)         # a fresh tensor per step: callers keep what step() returned
+            _lib.check(L.emap_train_loss(_lib.ptr(stats), self.edge_weight / n_glob, self.igr_weight, self.igr_ns_weight, _lib.ptr(out), st),
+                       "train_loss")
+        self.last_stats = out
+        return out
+
     def step(self, rays: Dict, true_edge: torch.Tensor, n_rays_global: Optional[int] = None):
         """One optimizer step on this rank's rays.  Returns the device tensor [loss, edge_loss] of the GLOBAL batch (no host
         synchronisation happens here)."""
+        if self.native_tail:
+            return self._step_native(rays, true_edge, n_rays_global)
         world = _world(self.group)
         call, v, edge, scalars = self._forward(rays)
         n_local = edge.numel()

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EMAP_ABI_VERSION 2
+#define EMAP_ABI_VERSION 3
 
 /* error codes */
 #define EMAP_OK 0
@@ -278,6 +278,24 @@ typedef struct EmapRayBatch {
 
 int emap_sample_rays(const EmapRayDataset* ds, int img_idx, int batch, int importance, uint64_t seed, uint64_t offset,
                      uint64_t* counter_dev, const int64_t* pixels_in, const EmapRayBatch* out, void* stream);
+
+/* ---- scalar tail of a training step (SURVEY par. 8 a15; src/runner/runner_udf.py:124-168, src/models/loss.py:14-17,
+ *      src/runner/runner_base.py:110-117) ---------------------------------------------------------------
+ * emap_train_stats : the rank-local statistics of a step and dL/d(edge) of EdgeLoss("mse") * edge_weight:
+ *                      d_edge[i] = (edge[i] - true_edge[i]) * d_scale          (d_scale = 2 * edge_weight / N_global; may be NULL)
+ *                      stats5    = [sum(relax), sum(near), sum(relax*err), sum(near*err), sum((edge - true_edge)^2)]
+ *                    with the eikonal sums taken from emap_render_fwd's `scalars` - the 5 numbers a data-parallel step sums
+ * emap_train_loss  : out2 = [loss, edge_loss] of runner_udf.py:124-159 from (globally summed) stats5:
+ *                      edge_loss = stats5[4] * w_over_n  (edge_weight / N_global),
+ *                      loss = edge_loss + igr * stats5[2] / (stats5[0] + 1e-5) + igr_ns * stats5[3] / (stats5[1] + 1e-5)
+ * emap_adam_step   : torch.optim.Adam([{geo params, lr_geo}, {the rest}], lr) (runner_base.py:110-117; betas / eps as given,
+ *                    no weight decay, no amsgrad) on flat buffers: elements [0, n_geo) use lr_geo, [n_geo, n) use lr.
+ *                    `step_dev` (float[1], starts at 0) counts the steps on the device and is incremented by the call. */
+int emap_train_stats(const float* edge, const float* true_edge, const float* scalars, int N, float d_scale, float* d_edge,
+                     float* stats5, void* stream);
+int emap_train_loss(const float* stats5, float w_over_n, float igr_weight, float igr_ns_weight, float* out2, void* stream);
+int emap_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* step_dev, int64_t n, int64_t n_geo,
+                   float lr_geo, float lr, float beta1, float beta2, float eps, void* stream);
 
 /* ---- dense-grid extraction (SURVEY par. 8 f2) ----------------------------------------------------
  * emap_null_direction : `_, _, vh = torch.linalg.svd(grad_ld); F.normalize(vh[:, -1, :])` of get_udf_normals_grid /

@@ -476,3 +476,43 @@ def test_training_loop_fits_a_multi_view_consistent_wire_frame():
     first, last = float(el[:50].mean()), float(el[-50:].mean())
     print(f"edge loss: first 50 steps {first:.4f}, last 50 steps {last:.4f}")
     assert torch.isfinite(el).all() and last < 0.5 * first
+
+
+@pytest.mark.gpu
+def test_native_adam_and_loss_tail_match_torch():
+    """emap_adam_step == torch.optim.Adam with the reference's two parameter groups (runner_base.py:110-117) on flat buffers;
+    emap_train_stats / emap_train_loss == the torch expressions of the step (runner_udf.py:124-159, loss.py:14-17)."""
+    L = _lib.lib()
+    g = torch.Generator(device="cpu").manual_seed(3)
+    n, n_geo = 10007, 7001
+    p0 = torch.randn(n, generator=g)
+    pa = torch.nn.Parameter(p0[:n_geo].clone().to(DEV)); pb = torch.nn.Parameter(p0[n_geo:].clone().to(DEV))
+    opt = torch.optim.Adam([{"params": [pa], "lr": 1e-3}, {"params": [pb]}], lr=5e-3)
+    p = p0.clone().to(DEV); m = torch.zeros(n, device=DEV); v = torch.zeros(n, device=DEV); t = torch.zeros(1, device=DEV)
+    for k in range(6):
+        gr = (torch.randn(n, generator=g) * (10.0 ** (k - 3))).to(DEV)
+        pa.grad, pb.grad = gr[:n_geo].clone(), gr[n_geo:].clone()
+        opt.step()
+        _lib.check(L.emap_adam_step(_lib.ptr(p), _lib.ptr(gr), _lib.ptr(m), _lib.ptr(v), _lib.ptr(t), n, n_geo, 1e-3, 5e-3, 0.9, 0.999, 1e-8,
+                                    _lib.stream_ptr(DEV)), "adam_step")
+    torch.cuda.synchronize()
+    ref = torch.cat([pa.detach(), pb.detach()])
+    assert float(t) == 6.0
+    assert float((p - ref).abs().max()) <= 2e-6, float((p - ref).abs().max())     # |update| <= lr per step; fp32 rounding of the same formula
+    # statistics and loss scalars
+    N = 333
+    edge, te = torch.rand(N, generator=g).to(DEV), torch.rand(N, generator=g).to(DEV)
+    sc = torch.rand(16, generator=g).to(DEV) + 0.5
+    d_edge, stats, out = torch.empty(N, device=DEV), torch.empty(5, device=DEV), torch.empty(2, device=DEV)
+    n_glob, w, igr, igr_ns = 2 * N, 0.7, 0.1, 0.05
+    _lib.check(L.emap_train_stats(_lib.ptr(edge), _lib.ptr(te), _lib.ptr(sc), N, 2.0 * w / n_glob, _lib.ptr(d_edge), _lib.ptr(stats),
+                                  _lib.stream_ptr(DEV)), "train_stats")
+    _lib.check(L.emap_train_loss(_lib.ptr(stats), w / n_glob, igr, igr_ns, _lib.ptr(out), _lib.stream_ptr(DEV)), "train_loss")
+    torch.cuda.synchronize()
+    diff = edge - te
+    assert torch.allclose(d_edge, diff * (2.0 * w / n_glob), rtol=1e-6, atol=0)
+    ref_stats = torch.stack([sc[4], sc[6], sc[3], sc[5], (diff.double() ** 2).sum().float()])
+    assert torch.allclose(stats, ref_stats, rtol=1e-6)
+    el = ref_stats[4] / n_glob * w
+    ref_loss = el + igr * ref_stats[2] / (ref_stats[0] + 1e-5) + igr_ns * ref_stats[3] / (ref_stats[1] + 1e-5)
+    assert torch.allclose(out, torch.stack([ref_loss, el]), rtol=1e-6)
