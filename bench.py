@@ -26,6 +26,7 @@ Prints ONE JSON line on rank 0, including
 """
 import argparse
 import ctypes as C
+import gc
 import json
 import os
 import socket
@@ -323,8 +324,12 @@ def main():
         step()
     for _ in range(a.warmup):
         step()
-    barrier()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    # no cyclic-GC pause inside the timed region: the host runs only a few ms ahead of the GPU at 0.65 ms per step, and a generation-2
+    # collection (tens of ms with torch's object graph) would starve the queue
+    gc.collect()
+    gc.disable()
+    barrier()
     t0 = time.perf_counter()
     for s_ev, e_ev in evs:
         s_ev.record()
@@ -332,6 +337,7 @@ def main():
         e_ev.record()
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
     r.check_errors()
     per_step = sorted(s_ev.elapsed_time(e_ev) for s_ev, e_ev in evs)
     med_ms = per_step[len(per_step) // 2]
@@ -418,15 +424,19 @@ def main():
                     continue
                 try:
                     r.precision = mode
-                    for _ in range(5):
+                    for _ in range(10):
                         eager_step()
                     torch.cuda.synchronize()
-                    t1 = time.perf_counter()
+                    # median of per-step event times: these short secondary runs otherwise pick up one-off stalls (a first-use code
+                    # object load or an allocator trim of ~70 ms landed in one of them in about every second run)
                     n_o = max(20, a.steps // 4)
-                    for _ in range(n_o):
+                    evo = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_o)]
+                    for s_ev, e_ev in evo:
+                        s_ev.record()
                         eager_step()
+                        e_ev.record()
                     torch.cuda.synchronize()
-                    dto = (time.perf_counter() - t1) / n_o
+                    dto = sorted(s_ev.elapsed_time(e_ev) for s_ev, e_ev in evo)[n_o // 2] * 1e-3
                     pm = measure_parity(dev, mode) if not a.no_parity else {}
                     other[mode] = {"value": rays * S / dto, "ms_per_step": dto * 1e3, "udf_rel_err": pm.get("udf_rel_err"),
                                    "grad_rel_err": pm.get("grad_rel_err"), "edge_rel_err": pm.get("edge_rel_err"),
