@@ -352,7 +352,11 @@ __device__ __forceinline__ float wave_sum_f(float v) {
 // 4 consecutive output rows per wave: they are the 4 accumulator registers of one lane of the MFMA output, i.e. ONE 16-byte
 // word of the partial blocks per (column, slice) - every load is a float4 and a wave reads 256-byte runs.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const ReduceArgs a) {
-    const int grp = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // one workgroup per group of 4 rows: its 4 waves each sum every 4th K-slice (there are only ~500 groups: with one wave per group
+    // the kernel was a latency chain on two waves per CU), wave 0 adds the four partial sums in a fixed order and finishes the rows
+    __shared__ f32x4 part[3][6][64];
+    const int grp = blockIdx.x;
+    const int wv = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
     if (grp >= a.row_off[a.n_lin]) return;       // row_off counts groups of 4 rows here
     int l = 0;
@@ -405,7 +409,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const ReduceArgs a) {
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) sum[c] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
-    for (int q = 0; q < nmax; ++q) {           // fixed order per column: deterministic
+    for (int q = wv; q < nmax; q += 4) {       // fixed order per column and wave: deterministic
         f32x4 v[MAXC];
 #pragma unroll
         for (int c = 0; c < MAXC; ++c)         // unconditional loads (a column with fewer slices re-reads its last one): they issue as one batch
@@ -416,6 +420,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const ReduceArgs a) {
             sum[c] += (q < ns[c]) ? v[c] : z;
         }
     }
+    if (wv > 0) {
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) part[wv - 1][c][lane] = sum[c];
+    }
+    __syncthreads();
+    if (wv > 0) return;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) sum[c] += (part[0][c][lane] + part[1][c][lane]) + part[2][c][lane];
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
         const int k = lane + 64 * c;
@@ -579,7 +591,7 @@ int launch_wgrad_reduce(const NetLayout& L, const WgradJob* jobs, int n_jobs, co
     }
     a.row_off[L.n_lin] = rows;
     for (int i = 0; i < n_jobs; ++i) a.job[i] = jobs[i];
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rows), dim3(256), 0, st, a);
     return check_launch("wgrad_reduce");
 }
 
