@@ -50,8 +50,8 @@ __global__ __launch_bounds__(256) void rowscale_kernel(const PackArgs a) {
     }
 }
 
-__global__ __launch_bounds__(256) void pack_kernel(const PackArgs a) {
-    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;  // one thread per (fragment, lane)
+__device__ __forceinline__ void pack_body(const PackArgs& a, unsigned block) {
+    const long long gid = (long long)block * 256 + threadIdx.x;  // one thread per (fragment, lane)
     const long long F = gid >> 6;
     const int lane = (int)(gid & 63);
     if (F >= a.L.total_frags) return;
@@ -118,8 +118,8 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackArgs a) {
 //   PE rows:     row (tile tau = 2*pp + t, i = 4*gc + r) is PE slot (sp = pp, gc, e = 4*t + r) - the slot lane group gc
 //                itself produced in the forward PE block;
 //   k element (s, g, e) is output feature 16*(2s + e/4) + 4g + e%4 of layer l (the usual permutation).
-__global__ __launch_bounds__(256) void pack_t_kernel(const PackArgs a) {
-    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void pack_t_body(const PackArgs& a, unsigned block) {
+    const long long gid = (long long)block * 256 + threadIdx.x;
     const long long F = gid >> 6;
     const int lane = (int)(gid & 63);
     if (F >= a.L.t_total_frags) return;
@@ -190,8 +190,8 @@ __global__ __launch_bounds__(256) void pack_t_kernel(const PackArgs a) {
 }
 
 // fp32 copy of the last layer's real row (times its weight-norm scale): the seed of the reverse sweep
-__global__ __launch_bounds__(256) void pack_wlast_kernel(const PackArgs a) {
-    const int f = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void pack_wlast_body(const PackArgs& a, unsigned block) {
+    const int f = block * 256 + threadIdx.x;
     const int H = a.L.H, l = a.L.n_lin - 1;
     if (f >= H) return;
     const float* rs = reinterpret_cast<const float*>(a.packed + a.L.rowscale_off_bytes);
@@ -268,6 +268,13 @@ void build_vjp_layout(const NetLayout& L, VjpLayout* V) {
     V->s_slab_kb = (L.n_lin - 1) * (L.H / 32) * 4;   // per workgroup: [hidden layer][tile pair][4 x 64 lanes x 16 B] lane-linear (a', sigma')
 }
 
+__global__ __launch_bounds__(256) void pack_all_kernel(const PackArgs a, unsigned nb0, unsigned nb1) {
+    const unsigned b = blockIdx.x;
+    if (b < nb0) pack_body(a, b);
+    else if (b < nb0 + nb1) pack_t_body(a, b - nb0);
+    else pack_wlast_body(a, b - nb0 - nb1);
+}
+
 int launch_pack(const NetLayout& L, const float* const* g, const float* const* v, const float* const* b,
                 void* packed, hipStream_t st) {
     PackArgs a;
@@ -280,12 +287,11 @@ int launch_pack(const NetLayout& L, const float* const* g, const float* const* v
     const int rows = L.n_lin * L.H;
     hipLaunchKernelGGL(rowscale_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, a);
     const long long threads = (long long)L.total_frags * 64;
-    hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, a);
-    {
-        const long long tthreads = (long long)L.t_total_frags * 64;
-        hipLaunchKernelGGL(pack_t_kernel, dim3((unsigned)((tthreads + 255) / 256)), dim3(256), 0, st, a);
-        hipLaunchKernelGGL(pack_wlast_kernel, dim3((L.H + 255) / 256), dim3(256), 0, st, a);
-    }
+    // forward fragments, transposed fragments and the last layer's fp32 row in ONE launch (they only depend on the row scales): the
+    // training step re-packs after every optimizer update, and each launch of these small kernels is ~5 us of latency
+    const long long tthreads = (long long)L.t_total_frags * 64;
+    const unsigned nb0 = (unsigned)((threads + 255) / 256), nb1 = (unsigned)((tthreads + 255) / 256), nb2 = (unsigned)((L.H + 255) / 256);
+    hipLaunchKernelGGL(pack_all_kernel, dim3(nb0 + nb1 + nb2), dim3(256), 0, st, a, nb0, nb1);
     return check_launch("pack_weights");
 }
 

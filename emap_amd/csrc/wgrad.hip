@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const ReduceArgs a) {
             int jb, ct, n;
             if (k < in_prev) { jb = a.job_h[l]; ct = k >> 4; n = k & 15; }
             else {
-                // natural PE column -> slot (sp, g, e) of the PE block (udf_mlp.hip:pack_kernel) -> row tile 2*sp + e/4, row 4g + e%4
+                // natural PE column -> slot (sp, g, e) of the PE block (udf_mlp.hip:pack_body) -> row tile 2*sp + e/4, row 4g + e%4
                 const int pc = k - in_prev, M = a.multires;
                 int ang, kind;
                 if (pc < 3) { ang = (pc == 2) ? 3 * M + 1 : 3 * M; kind = (pc == 1) ? 1 : 0; }
