@@ -64,7 +64,9 @@ def parse():
     ap.add_argument("--precision", default=os.environ.get("EMAP_BENCH_PRECISION", "f16x3"), choices=list(MODE_DTYPE),
                     help="arithmetic of the MLP GEMMs for `value`; f16x3 is the mode that meets the 1e-4 parity gate")
     ap.add_argument("--eikonal-sync", default="exact", choices=["exact", "local"], help="train mode, N > 1 (emap_amd/parallel.py)")
-    ap.add_argument("--graph", default="off", choices=["on", "off"], help="replay the step from a captured hipGraph")
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+                    help="replay the step from a captured hipGraph (auto: render mode yes - falling back to eager launches if the "
+                         "capture fails -, train mode no)")
     ap.add_argument("--settle-steps", type=int, default=150, help="untimed steps before the warm-up steps (clock settle)")
     ap.add_argument("--no-other-modes", action="store_true", help="skip the short runs of the other precision modes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -275,10 +277,12 @@ def main():
     # hipGraph: the launch chain of a step (15 kernels forward, +8 backward, + torch's elementwise / Adam kernels) replays as one
     # graph launch.  Multi-rank training keeps eager launches unless --graph on (an RCCL collective inside a captured graph is
     # not something this build could test on its one-GPU boxes).
-    # Measured on MI355X (round 2, same box): replay and eager launches give the same step time (render 0.70 vs 0.70 ms, train 2.39
-    # vs 2.39 ms): the stream is GPU-bound and the launches are hidden behind the kernels, so eager stays the default.
+    # Measured on MI355X (round 2, same box): in a long loop replay and eager launches give the same step time (render 0.70 vs 0.70
+    # ms, train 2.39 vs 2.39 ms at 200 steps): the stream is GPU-bound and the launches hide behind the kernels.  A timed region that
+    # is bracketed by synchronisations starts with an empty queue, though, and with 20 steps the host-bound first step is 2 % of it
+    # (0.789 vs 0.773 ms per step): the forward render replays from a graph by default, the training step stays eager.
     step, launch = eager_step, "eager"
-    want_graph = a.graph == "on"
+    want_graph = a.graph == "on" or (a.graph == "auto" and a.mode == "render")
     if want_graph:
         try:
             if a.mode == "train":
