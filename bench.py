@@ -354,13 +354,15 @@ def main():
     # events around the dominant kernel - not in the headline loop
     which = 1 if a.mode == "train" else 0
     _lib.check(L.emap_profile_enable(1))
-    for _ in range(min(a.steps, 20)):
+    n_prof = min(a.steps, 20)
+    for _ in range(n_prof):
         eager_step()
     torch.cuda.synchronize()
     _lib.check(L.emap_profile_enable(0))
     kms, kn = C.c_float(), C.c_int()
     _lib.check(L.emap_profile_read_kernel(which, C.byref(kms), C.byref(kn)))
     k_avg_s = (kms.value / max(kn.value, 1)) * 1e-3
+    launches_per_step = max(kn.value, 1) / n_prof      # > 1 when the backward sweep runs in chunks of 65 536 points (> 512 rays per GPU)
     loss_now = trainer.last_stats.tolist() if trainer is not None else None
 
     if rank == 0:
@@ -369,7 +371,7 @@ def main():
         if a.mode == "train":
             # dominant kernel: the per-point sweep of the MLP double backward (value + one tangent column forward, two adjoint
             # columns backward) = 2F + 2F of the 6F the backward has to do per point; the weight-gradient GEMMs are a second kernel
-            flops_launch = rays * S * 4 * F_POINT
+            flops_launch = rays * S * 4 * F_POINT / launches_per_step
             dominant = f"udf_mlp_vjp_kernel<256,{a.precision},8> (forward recompute + reverse sweep of the double backward)"
             alg = A_TRAIN
             metric = "ray-samples/sec (training step: render fwd + HIP bwd + all-reduce + Adam)"
@@ -378,7 +380,7 @@ def main():
         else:
             # dominant kernel: the value+grad MLP launch over rays*S points; algorithmic work = value + reverse-mode input
             # gradient = 2F per point (SURVEY par. 8d)
-            flops_launch = rays * S * 2 * F_POINT
+            flops_launch = rays * S * 2 * F_POINT / launches_per_step
             rev = rays * S >= (10240 if a.precision in ("f16x3", "bf16x3") else 16384)
             dominant = (f"udf_mlp_rev_kernel<256,{a.precision}>" if rev else f"udf_mlp_fs2_kernel<256,{a.precision},4,grad>") + " (final value+grad pass)"
             alg = A_FWD
@@ -416,7 +418,10 @@ def main():
         if os.path.exists(tpath):
             try:
                 ent = json.load(open(tpath)).get(f"{a.mode}:{a.precision}")
-                if ent:
+                # the counters were collected on launches of 65 536 points (512 rays x 128 samples; the backward sweep runs in chunks
+                # of that size whatever the batch): no figure is quoted for a launch of another size
+                same_launch = (rays * S == 65536) if a.mode == "render" else (rays * S >= 65536 and (rays * S) % 65536 == 0)
+                if ent and same_launch:
                     line["roofline"]["traffic"] = ent["hbm_bytes_per_launch"]
                     line["roofline"]["traffic_source"] = "profiles/r02_traffic.json (rocprofv3 --pmc passes of this kernel, MI355X_MICROARCH.md corrections)"
             except Exception:
