@@ -69,13 +69,16 @@ struct NetLayout {
     // covered (skip layer == last layer): the forward-mode kernels are used then.
     int32_t has_rev, t_total_frags, t_frag_off_bytes, wlast_off_bytes;
     int32_t t_off[EMAP_MAX_LIN], tpe_off[EMAP_MAX_LIN];
+    // the same two fragment sets in the K order of the 32x32x16 kernels (udf_mlp_rev32.inc): same fragment counts and the
+    // same per-layer offsets (frag_off, t_off, tpe_off), a fragment = 32 rows x 16 k, index [row tile][K32-step][u][part]
+    int32_t r32_frag_off_bytes, r32_t_frag_off_bytes;
     LayerDesc layer[EMAP_MAX_LIN];
 };
 
 // returns 0 or EMAP_E_INVALID (error text set)
 int build_layout(const EmapNetConfig* cfg, int prec, NetLayout* L);
 inline size_t layout_bytes(const NetLayout& L) {
-    return (size_t)L.t_frag_off_bytes + (size_t)L.t_total_frags * FRAG_BYTES;
+    return (size_t)L.r32_t_frag_off_bytes + (size_t)L.t_total_frags * FRAG_BYTES;
 }
 
 // launchers implemented in the .hip files

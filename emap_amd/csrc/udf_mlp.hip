@@ -189,6 +189,126 @@ __device__ __forceinline__ void pack_t_body(const PackArgs& a, unsigned block) {
     else *reinterpret_cast<bf16x8*>(dst) = outv;
 }
 
+
+// ---- fragments in the K order of the 32x32x16 kernels (udf_mlp_rev32.inc) -------------------------------------------------
+// A operand of v_mfma_f32_32x32x16: lane (hh = lane>>5, i = lane&31) holds row i, k = 8*hh + e.  One fragment = 32 output
+// features x 16 k; fragment order = layer, row tile p, K32-step S (PE block first), u (K16 half), part (hi, lo).
+//   hidden k-slot (S, u, hh, e) = feature 32S + (e&3) + 8(2u + (e>>2)) + 4hh  (register r = 8u + e of the lane's C fragment)
+//   PE k-slot (S, u, hh, e): angle index 16hh + 8S + 4u + (e>>1), kind (sin|cos) = e&1
+__device__ __forceinline__ int pe_col_of(int ang, int kind, int M, int d0) {
+    int pcol = -1;
+    if (ang < 3 * M) {
+        const int k = ang / 3, c = ang - 3 * k;
+        pcol = 3 + 6 * k + (kind ? 3 + c : c);
+    } else if (ang == 3 * M) {
+        pcol = kind ? 1 : 0;
+    } else if (ang == 3 * M + 1) {
+        pcol = kind ? -1 : 2;
+    }
+    return (pcol >= 0 && pcol < d0) ? pcol : -1;
+}
+__device__ __forceinline__ void store_frag(const PackArgs& a, char* dst, const float (&w)[8], int part) {
+    bf16x8 outv;
+    f16x8 outh;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const __bf16 hi = (__bf16)w[e];
+        outv[e] = (part == 0) ? hi : (__bf16)(w[e] - (float)hi);
+        const _Float16 hh = (_Float16)w[e];
+        outh[e] = (part == 0) ? hh : (_Float16)((w[e] - (float)hh) * 2048.0f);  // lo parts scaled by 2^11 (split-fp16)
+    }
+    if (a.L.is_f16) *reinterpret_cast<f16x8*>(dst) = outh;
+    else *reinterpret_cast<bf16x8*>(dst) = outv;
+}
+
+__device__ __forceinline__ void pack32_body(const PackArgs& a, unsigned block) {
+    const long long gid = (long long)block * 256 + threadIdx.x;  // one thread per (fragment, lane)
+    const long long F = gid >> 6;
+    const int lane = (int)(gid & 63);
+    if (F >= a.L.total_frags) return;
+    int l = 0;
+    while (l + 1 < a.L.n_lin && F >= a.L.layer[l + 1].frag_off) ++l;
+    const LayerDesc Ld = a.L.layer[l];
+    const int H = a.L.H, NP = a.L.nparts, d0 = a.L.d0, M = a.L.multires;
+    int idx = (int)(F - Ld.frag_off);
+    const int part = idx % NP; idx /= NP;
+    const int u = idx & 1; idx >>= 1;
+    const int n_ks = Ld.pe_ks + Ld.h_ks;
+    const int S = idx % n_ks;
+    const int p = idx / n_ks;
+    const int i = lane & 31, hh = lane >> 5;
+    const int o = 32 * p + i;
+    const float* rs = reinterpret_cast<const float*>(a.packed + a.L.rowscale_off_bytes);
+    const float mult = (l == a.L.skip_l) ? 0.70710678118654752440f : 1.0f;  // cat([x, PE]) / sqrt(2), udf_model.py:100
+    const int n_in = a.in_dim[l];
+    float w[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        int col = -1;
+        if (S < Ld.pe_ks) {
+            const int pcol = pe_col_of(16 * hh + 8 * S + 4 * u + (e >> 1), e & 1, M, d0);
+            if (pcol >= 0) col = (l == 0) ? pcol : Ld.in_prev + pcol;
+        } else {
+            const int f = 32 * (S - Ld.pe_ks) + (e & 3) + 8 * (2 * u + (e >> 2)) + 4 * hh;
+            if (f < Ld.in_prev) col = f;
+        }
+        w[e] = (o < Ld.out_dim && col >= 0 && col < n_in) ? rs[l * H + o] * a.v[l][(size_t)o * n_in + col] * mult : 0.f;
+    }
+    store_frag(a, a.packed + a.L.r32_frag_off_bytes + F * FRAG_BYTES + lane * 16, w, part);
+}
+
+// Transposed fragments of the 32x32x16 reverse sweep: A operand of  delta_in = W_l^T * delta_z_l.
+//   hidden rows: row i of row tile p is input feature 32p + i of layer l (natural order = the A-operand row, so the C
+//                fragment of the backward GEMM lines up lane for lane with the sigma' the forward sweep stashed);
+//   PE rows:     row i of tile tau: hc = (i>>2)&1, r = (i&3) + 4(i>>3)  ->  PE slot (S = tau, u = r>>3, hc, e = r&7), the slot
+//                lane half hc holds in register r of its C fragment and in its own PE fragment;
+//   k element (S, u, hh, e) is output feature 32S + (e&3) + 8(2u + (e>>2)) + 4hh of layer l.
+__device__ __forceinline__ void pack32_t_body(const PackArgs& a, unsigned block) {
+    const long long gid = (long long)block * 256 + threadIdx.x;
+    const long long F = gid >> 6;
+    const int lane = (int)(gid & 63);
+    if (F >= a.L.t_total_frags) return;
+    const int H = a.L.H, NP = a.L.nparts, d0 = a.L.d0, M = a.L.multires, NKS = H / 32;
+    int l = -1; bool pe = false; int base = 0;
+    for (int q = 0; q < a.L.n_lin; ++q) {
+        if (q >= 1 && q < a.L.n_lin - 1) {
+            const int n = ((a.L.layer[q].in_prev + 31) / 32) * NKS * 2 * NP;
+            if (F >= a.L.t_off[q] && F < a.L.t_off[q] + n) { l = q; pe = false; base = a.L.t_off[q]; }
+        }
+        if (q == 0 || q == a.L.skip_l) {
+            const int n = 2 * NKS * 2 * NP;
+            if (F >= a.L.tpe_off[q] && F < a.L.tpe_off[q] + n) { l = q; pe = true; base = a.L.tpe_off[q]; }
+        }
+    }
+    if (l < 0) return;
+    const LayerDesc Ld = a.L.layer[l];
+    int idx = (int)(F - base);
+    const int part = idx % NP; idx /= NP;
+    const int u = idx & 1; idx >>= 1;
+    const int S = idx % NKS;
+    const int p = idx / NKS;
+    const int i = lane & 31, hh = lane >> 5;
+    const float* rs = reinterpret_cast<const float*>(a.packed + a.L.rowscale_off_bytes);
+    const float mult = (l == a.L.skip_l) ? 0.70710678118654752440f : 1.0f;
+    const int n_in = a.in_dim[l];
+    int col = -1;   // column of W_l this row stands for
+    if (!pe) {
+        const int f = 32 * p + i;
+        if (f < Ld.in_prev) col = f;
+    } else {
+        const int hc = (i >> 2) & 1, r = (i & 3) + 4 * (i >> 3);
+        const int pcol = pe_col_of(16 * hc + 8 * p + 4 * (r >> 3) + ((r & 7) >> 1), r & 1, M, d0);
+        if (pcol >= 0) col = (l == 0) ? pcol : Ld.in_prev + pcol;
+    }
+    float w[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int o = 32 * S + (e & 3) + 8 * (2 * u + (e >> 2)) + 4 * hh;
+        w[e] = (o < Ld.out_dim && col >= 0 && col < n_in) ? rs[l * H + o] * a.v[l][(size_t)o * n_in + col] * mult : 0.f;
+    }
+    store_frag(a, a.packed + a.L.r32_t_frag_off_bytes + F * FRAG_BYTES + lane * 16, w, part);
+}
+
 // fp32 copy of the last layer's real row (times its weight-norm scale): the seed of the reverse sweep
 __device__ __forceinline__ void pack_wlast_body(const PackArgs& a, unsigned block) {
     const int f = block * 256 + threadIdx.x;
@@ -248,6 +368,8 @@ int build_layout(const EmapNetConfig* cfg, int prec, NetLayout* L) {
         if (l == 0 || l == cfg->skip_l) { L->tpe_off[l] = tf; tf += 2 * (H / 32) * 2 * L->nparts; }
     }
     L->t_total_frags = tf;   // always packed: the training backward (udf_mlp_vjp.inc) needs it for every topology
+    L->r32_frag_off_bytes = L->t_frag_off_bytes + tf * FRAG_BYTES;
+    L->r32_t_frag_off_bytes = L->r32_frag_off_bytes + frag * FRAG_BYTES;
     return EMAP_OK;
 }
 
@@ -272,7 +394,9 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const PackArgs a, unsigne
     const unsigned b = blockIdx.x;
     if (b < nb0) pack_body(a, b);
     else if (b < nb0 + nb1) pack_t_body(a, b - nb0);
-    else pack_wlast_body(a, b - nb0 - nb1);
+    else if (b < 2 * nb0 + nb1) pack32_body(a, b - nb0 - nb1);
+    else if (b < 2 * (nb0 + nb1)) pack32_t_body(a, b - 2 * nb0 - nb1);
+    else pack_wlast_body(a, b - 2 * (nb0 + nb1));
 }
 
 int launch_pack(const NetLayout& L, const float* const* g, const float* const* v, const float* const* b,
@@ -291,7 +415,7 @@ int launch_pack(const NetLayout& L, const float* const* g, const float* const* v
     // training step re-packs after every optimizer update, and each launch of these small kernels is ~5 us of latency
     const long long tthreads = (long long)L.t_total_frags * 64;
     const unsigned nb0 = (unsigned)((threads + 255) / 256), nb1 = (unsigned)((tthreads + 255) / 256), nb2 = (unsigned)((L.H + 255) / 256);
-    hipLaunchKernelGGL(pack_all_kernel, dim3(nb0 + nb1 + nb2), dim3(256), 0, st, a, nb0, nb1);
+    hipLaunchKernelGGL(pack_all_kernel, dim3(2 * (nb0 + nb1) + nb2), dim3(256), 0, st, a, nb0, nb1);
     return check_launch("pack_weights");
 }
 
@@ -302,25 +426,26 @@ int launch_mlp_f16x3(const NetLayout&, const void*, const PointSource&, int64_t,
 
 // kernel variant: 0 = "classic" (column-split waves, weights shared through LDS, one wave per SIMD),
 // 1 = "fs" (feature-split waves, one workgroup per CU), 2 = "fs2" (feature-split, two/three workgroups per CU),
-// 3 = "rev" (grad launches only: fs2-shaped forward + reverse sweep, udf_mlp_rev.inc).
-// EMAP_MLP_KERNEL=classic|fs|fs2 forces one forward-mode variant, EMAP_GRAD_MODE=fwd|rev picks how d(udf)/dx is
+// 3 = "rev" (grad launches only: forward + reverse sweep on 32x32x16 MFMA tiles, udf_mlp_rev32.inc),
+// 4 = "rev16" (the same algorithm on 16x16x32 tiles, udf_mlp_rev.inc: the round-1/2 kernel, kept for same-box A/B).
+// EMAP_MLP_KERNEL=classic|fs|fs2 forces one forward-mode variant, EMAP_GRAD_MODE=fwd|rev|rev16 picks how d(udf)/dx is
 // computed (A/B measurements).
 static int mlp_variant(const NetLayout& L, int prec, int64_t P, bool grad) {
     // read on every call (two getenv, ~100 ns): the tests and the A/B scripts flip them inside one process
     const char* e = getenv("EMAP_MLP_KERNEL");
     const int forced = !e ? -1 : (!strcmp(e, "classic") ? 0 : (!strcmp(e, "fs") ? 1 : (!strcmp(e, "fs2") ? 2 : -1)));
     const char* gm = getenv("EMAP_GRAD_MODE");
-    const int grad_mode = !gm ? -1 : (!strcmp(gm, "fwd") ? 0 : (!strcmp(gm, "rev") ? 1 : -1));
+    const int grad_mode = !gm ? -1 : (!strcmp(gm, "fwd") ? 0 : (!strcmp(gm, "rev") ? 1 : (!strcmp(gm, "rev16") ? 2 : -1)));
     // reverse mode halves the MFMA work of a grad launch but a tile is two dependent sweeps: it wins once most CUs have a
     // workgroup (measured crossover: the split modes between 8k and 12k points, single-pass modes at 16k).
     const int64_t rev_min = (prec == EMAP_PREC_F16X3 || prec == EMAP_PREC_BF16X3) ? 10240 : 16384;
-    if (grad && L.has_rev && forced < 0 && grad_mode != 0 && (P >= rev_min || grad_mode == 1)) return 3;
+    if (grad && L.has_rev && forced < 0 && grad_mode != 0 && (P >= rev_min || grad_mode >= 1)) return grad_mode == 2 ? 4 : 3;
     if (forced >= 0) return forced;
     (void)prec; (void)P;
     return 2;   // fs2 (two or three workgroups per CU) measured fastest or equal at every size and mode on MI355X
 }
 
-bool mlp_uses_rev(const NetLayout& L, int prec, int64_t P) { return mlp_variant(L, prec, P, true) == 3; }
+bool mlp_uses_rev(const NetLayout& L, int prec, int64_t P) { return mlp_variant(L, prec, P, true) >= 3; }
 
 int launch_mlp(const NetLayout& L, const void* packed, int prec, const PointSource& src, int64_t P, float* udf,
                float* grad3, hipStream_t st, int32_t* err_flags, void* scratch) {

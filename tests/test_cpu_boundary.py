@@ -59,6 +59,7 @@ def test_packed_layout_size(H, n_lin, multires, prec, expect_frags, expect_tfrag
     expect = hdr + expect_frags * 1024
     if expect_tfrags is not None:
         expect += ((H * 4 + 1023) // 1024) * 1024 + expect_tfrags * 1024   # last layer's fp32 row + transposed fragments
+    expect += (expect_frags + expect_tfrags) * 1024   # both sets once more in the K order of the 32x32x16 kernels
     assert n.value == expect
 
 
