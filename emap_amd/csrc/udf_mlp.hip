@@ -427,7 +427,8 @@ int launch_mlp_f16x3(const NetLayout&, const void*, const PointSource&, int64_t,
 // kernel variant: 0 = "classic" (column-split waves, weights shared through LDS, one wave per SIMD),
 // 1 = "fs" (feature-split waves, one workgroup per CU), 2 = "fs2" (feature-split, two/three workgroups per CU),
 // 3 = "rev" (grad launches only: forward + reverse sweep on 32x32x16 MFMA tiles, udf_mlp_rev32.inc),
-// 4 = "rev16" (the same algorithm on 16x16x32 tiles, udf_mlp_rev.inc: the round-1/2 kernel, kept for same-box A/B).
+// 4 = "rev16" (the same algorithm on 16x16x32 tiles, udf_mlp_rev.inc: the round-1/2 kernel, kept for same-box A/B),
+// 5 = "rev128" (variant 3 with a 128-point tile: one 8-wave workgroup per CU).
 // EMAP_MLP_KERNEL=classic|fs|fs2 forces one forward-mode variant, EMAP_GRAD_MODE=fwd|rev|rev16 picks how d(udf)/dx is
 // computed (A/B measurements).
 static int mlp_variant(const NetLayout& L, int prec, int64_t P, bool grad) {
@@ -435,11 +436,11 @@ static int mlp_variant(const NetLayout& L, int prec, int64_t P, bool grad) {
     const char* e = getenv("EMAP_MLP_KERNEL");
     const int forced = !e ? -1 : (!strcmp(e, "classic") ? 0 : (!strcmp(e, "fs") ? 1 : (!strcmp(e, "fs2") ? 2 : -1)));
     const char* gm = getenv("EMAP_GRAD_MODE");
-    const int grad_mode = !gm ? -1 : (!strcmp(gm, "fwd") ? 0 : (!strcmp(gm, "rev") ? 1 : (!strcmp(gm, "rev16") ? 2 : -1)));
+    const int grad_mode = !gm ? -1 : (!strcmp(gm, "fwd") ? 0 : (!strcmp(gm, "rev") ? 1 : (!strcmp(gm, "rev16") ? 2 : (!strcmp(gm, "rev128") ? 3 : -1))));
     // reverse mode halves the MFMA work of a grad launch but a tile is two dependent sweeps: it wins once most CUs have a
     // workgroup (measured crossover: the split modes between 8k and 12k points, single-pass modes at 16k).
     const int64_t rev_min = (prec == EMAP_PREC_F16X3 || prec == EMAP_PREC_BF16X3) ? 10240 : 16384;
-    if (grad && L.has_rev && forced < 0 && grad_mode != 0 && (P >= rev_min || grad_mode >= 1)) return grad_mode == 2 ? 4 : 3;
+    if (grad && L.has_rev && forced < 0 && grad_mode != 0 && (P >= rev_min || grad_mode >= 1)) return grad_mode == 2 ? 4 : (grad_mode == 3 ? 5 : 3);
     if (forced >= 0) return forced;
     (void)prec; (void)P;
     return 2;   // fs2 (two or three workgroups per CU) measured fastest or equal at every size and mode on MI355X

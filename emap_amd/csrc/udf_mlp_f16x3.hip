@@ -6,7 +6,7 @@ int launch_mlp_f16x3(const NetLayout& L, const void* packed, const PointSource& 
 #if EMAP_F16X3_ONE_ACC
     if (variant < 2) variant = 2;   // the one-accumulator weight format is only implemented by the fs2 / reverse kernels
 #endif
-    if (variant == 3) return launch_mlp_rev32_mode<EMAP_PREC_F16X3>(L, packed, src, P, udf, grad3, st, err, scratch);
+    if (variant == 3 || variant == 5) return launch_mlp_rev32_mode<EMAP_PREC_F16X3>(L, packed, src, P, udf, grad3, st, err, scratch, variant == 5);
     if (variant == 4) return launch_mlp_rev_mode<EMAP_PREC_F16X3>(L, packed, src, P, udf, grad3, st, err, scratch);
     if (variant == 2) return launch_mlp_fs2_mode<EMAP_PREC_F16X3>(L, packed, src, P, udf, grad3, st, err);
     if (variant == 1) return launch_mlp_fs_mode<EMAP_PREC_F16X3>(L, packed, src, P, udf, grad3, st, err);

@@ -16,9 +16,13 @@ src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(root, "gpurun_out", f"profiles_{tag}")      # copied into profiles/ by hand after inspection
 os.makedirs(dst, exist_ok=True)
 # the kernels whose counters are reported, by mode
-KERNELS = {"render": {"udf_mlp_rev_kernel": "final value+grad MLP pass (reverse sweep)"},
+PER_RAY = {"sampler_step_kernel": "one fused importance-sampling step per launch (udf_renderer_blending.py:228-377)",
+           "composite_kernel": "render_core tail: alpha, visibility, weights, per-ray sums (udf_renderer_blending.py:418-677)",
+           "composite_reduce_kernel": "cross-ray reduction of the eikonal terms"}
+KERNELS = {"render": {"udf_mlp_rev": "final value+grad MLP pass (reverse sweep)", "udf_mlp_fs2_kernel": "value passes of the sampler", **PER_RAY},
            "train": {"udf_mlp_vjp_kernel": "MLP double-backward sweep", "wgrad_kernel": "weight-gradient GEMMs",
-                     "udf_mlp_rev_kernel": "final value+grad MLP pass (reverse sweep)"}}[mode]
+                     "udf_mlp_rev": "final value+grad MLP pass (reverse sweep)", "composite_bwd_kernel": "adjoint of the render_core tail",
+                     **PER_RAY}}[mode]
 
 
 def find(pat):
@@ -74,7 +78,7 @@ if out:
     print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk != "counters"} for k, v in out.items()}, indent=1))
     tpath = os.path.join(dst, f"{tag}_traffic.json")
     tj = json.load(open(tpath)) if os.path.exists(tpath) else {}
-    dom = "udf_mlp_vjp_kernel" if mode == "train" else "udf_mlp_rev_kernel"
+    dom = "udf_mlp_vjp_kernel" if mode == "train" else "udf_mlp_rev"
     if dom in traffic:
         tj[f"{mode}:{prec}"] = {"hbm_bytes_per_launch": traffic[dom], "kernel": dom, "all": traffic}
         json.dump(tj, open(tpath, "w"), indent=1)
