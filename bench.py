@@ -68,6 +68,10 @@ def parse():
                     help="replay the step from a captured hipGraph (auto: render mode yes - falling back to eager launches if the "
                          "capture fails -, train mode no)")
     ap.add_argument("--settle-steps", type=int, default=150, help="untimed steps before the warm-up steps (clock settle)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for N > 1: nccl (= RCCL, one rank per GPU) or gloo (debug: the ranks share the visible "
+                         "GPUs round-robin and reduce through the host - runs every line of the N > 1 path on a one-GPU box)")
+    ap.add_argument("--no-train-key", action="store_true", help="render mode, one GPU: skip the short training-step measurement")
     ap.add_argument("--no-other-modes", action="store_true", help="skip the short runs of the other precision modes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
@@ -75,7 +79,7 @@ def parse():
     return ap.parse_args()
 
 
-def relaunch_under_launcher(n):
+def relaunch_under_launcher(n, backend="nccl"):
     """`python bench.py --gpus N` without a launcher: spawn N ranks (one per GPU) and pass their output through."""
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
@@ -131,6 +135,57 @@ def measure_parity(dev, precision):
         o = r.render(*a, cos_anneal_ratio=1.0, perturb_overwrite=0, flip_saturation=0.9)
     out["edge_rel_err"] = rel(o["edge"], torch.from_numpy(g5["out.edge"]))
     out["meets_1e-4"] = bool(out["udf_rel_err"] <= 1e-4 and out["grad_rel_err"] <= 1e-4 and out["edge_rel_err"] <= 1e-4)
+    return out
+
+
+def train_key(dev, precision, rays, S, steps=40, warmup=10):
+    """Short measurement of the OPTIMIZER STEP (forward + HIP backward + fused Adam, rays drawn on the device) appended to the
+    default render line so that the driver's own run times it: ms per step, ray-samples/s, fraction of the MFMA peak for the
+    algorithmic A_TRAIN FLOP per ray-sample, HBM traffic per step (static, from profiles/)."""
+    import emap_amd
+    from emap_amd import synthetic
+    from emap_amd.parallel import Trainer
+    r, _, _ = build_renderer(dev, precision)
+    trainer = Trainer(r, lr_geo=1e-4, lr=5e-4, edge_weight=1.0, igr_weight=0.1, igr_ns_weight=0.0)
+    meta, edges = synthetic.make_scene(n_images=8, H=400, W=400, seed=3)
+    sampler = emap_amd.DeviceRaySampler.from_meta(meta, edges, device=dev, seed=1000)
+    sampler.set_image_perm(list(range(8)))
+    near_f, far_f = float(meta["scene_box"]["near"]), float(meta["scene_box"]["far"])
+
+    def step():
+        smp = sampler.gen_random_rays_patches_at(None, rays, importance_sample=True)
+        batch = {"rays_o": smp["rays"]["rays_o"], "rays_d": smp["rays"]["rays_v"], "near": near_f, "far": far_f,
+                 "depth_scale": smp["depth_scale"], "cos_anneal_ratio": 1.0, "flip_saturation": 0.9,
+                 "t_rand": torch.rand(rays, 1, device=dev) - 0.5}
+        return trainer.step(batch, smp["rays"]["edge"], n_rays_global=rays)
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for s_ev, e_ev in evs:
+        s_ev.record()
+        step()
+        e_ev.record()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    r.check_errors()
+    med = sorted(s_ev.elapsed_time(e_ev) for s_ev, e_ev in evs)[steps // 2]
+    value = rays * S / dt
+    out = {"metric": "ray-samples/sec (training step: render fwd + HIP bwd + Adam)", "steps": steps, "warmup": warmup,
+           "ms_per_step": dt * 1e3, "ms_per_step_median": med, "value": value, "unit": "ray-samples/s",
+           "whole_step_algorithmic_tflops": value * A_TRAIN / 1e12, "whole_step_frac": value * A_TRAIN / 1e12 / MFMA_PEAK_TFLOPS,
+           "launch": "eager", "loss_after_run": trainer.last_stats.tolist(), "traffic": None}
+    tpath = os.path.join(ROOT, "profiles", "r03_traffic.json")
+    if os.path.exists(tpath) and rays * S == 65536:
+        try:
+            ent = json.load(open(tpath)).get(f"train:{precision}")
+            if ent:
+                out["traffic"] = sum(ent.get("all", {}).values()) or ent.get("hbm_bytes_per_launch")
+                out["traffic_source"] = "STATIC: profiles/r03_traffic.json (sum over the step's MLP / weight-gradient kernels, rocprofv3 --pmc), not measured in this run"
+        except Exception:
+            pass
     return out
 
 
@@ -217,21 +272,25 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     launched = "WORLD_SIZE" in os.environ
     if a.gpus > 1 and not launched:
-        if torch.cuda.device_count() < a.gpus:
+        if torch.cuda.device_count() < a.gpus and a.backend == "nccl":
             raise SystemExit(f"bench.py --gpus {a.gpus}: only {torch.cuda.device_count()} GPU(s) visible")
-        sys.exit(relaunch_under_launcher(a.gpus))
+        sys.exit(relaunch_under_launcher(a.gpus, a.backend))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
         raise SystemExit(f"bench.py --gpus {a.gpus} was launched with WORLD_SIZE={world}: refusing to report n_gpus != ranks")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    device_index = local_rank if a.backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
         assert dist.get_world_size() == a.gpus
 
     from emap_amd import synthetic, _lib
@@ -285,7 +344,20 @@ def main():
     want_graph = a.graph == "on" or (a.graph == "auto" and a.mode == "render")
     if want_graph:
         try:
-            if a.mode == "train":
+            if a.mode == "train" and world > 1:
+                # several ranks: one graph per device phase, the collectives launched between the replays (Trainer.capture); the
+                # rays are still drawn per step, outside the graphs, and copied into the static batch
+                smp0 = sampler.gen_random_rays_patches_at(None, rays, importance_sample=True)
+                batch0 = {"rays_o": smp0["rays"]["rays_o"], "rays_d": smp0["rays"]["rays_v"], "near": near_f, "far": far_f,
+                          "depth_scale": smp0["depth_scale"], "cos_anneal_ratio": 1.0, "flip_saturation": 0.9,
+                          "t_rand": torch.rand(rays, 1, device=dev) - 0.5}
+                replay = trainer.capture(batch0, smp0["rays"]["edge"], n_rays_global=rays * world, segmented=True)
+
+                def step():
+                    smp = sampler.gen_random_rays_patches_at(None, rays, importance_sample=True)
+                    return replay({"rays_o": smp["rays"]["rays_o"], "rays_d": smp["rays"]["rays_v"], "depth_scale": smp["depth_scale"],
+                                   "t_rand": torch.rand(rays, 1, device=dev) - 0.5}, smp["rays"]["edge"])
+            elif a.mode == "train":
                 side = torch.cuda.Stream(device=dev)
                 side.wait_stream(torch.cuda.current_stream(dev))
                 with torch.cuda.stream(side):
@@ -301,7 +373,7 @@ def main():
                     return graph_out
             else:
                 step = r.capture(ro, rd, near, far, ds, cos_anneal_ratio=1.0, flip_saturation=0.9, t_rand=tr)
-            launch = "hipGraph replay"
+            launch = "hipGraph replay" if not (a.mode == "train" and world > 1) else "hipGraph replay per phase, eager collectives"
         except Exception as e:   # pragma: no cover
             if a.graph == "on":
                 raise
@@ -382,7 +454,7 @@ def main():
             # gradient = 2F per point (SURVEY par. 8d)
             flops_launch = rays * S * 2 * F_POINT / launches_per_step
             rev = rays * S >= (10240 if a.precision in ("f16x3", "bf16x3") else 16384)
-            dominant = (f"udf_mlp_rev_kernel<256,{a.precision}>" if rev else f"udf_mlp_fs2_kernel<256,{a.precision},4,grad>") + " (final value+grad pass)"
+            dominant = (f"udf_mlp_rev32_kernel<256,{a.precision}>" if rev else f"udf_mlp_fs2_kernel<256,{a.precision},4,grad>") + " (final value+grad pass)"
             alg = A_FWD
             metric = "ray-samples/sec (UDF MLP + composite)"
             workload = "forward render()"
@@ -399,9 +471,11 @@ def main():
                        "parallelism": f"dp{world} over rays" + (", no collective in forward" if a.mode == "render" else
                                                                f", {trainer.collectives_per_step} collective(s) per step "
                                                                f"(eikonal_sync={a.eikonal_sync}: "
-                                                               + ("20 B stats + " if a.eikonal_sync == "exact" and world > 1 else "")
+                                                               + ("20 B statistics (SUM) + 8 B range maxima (MAX) + " if a.eikonal_sync == "exact" and world > 1 else "")
                                                                + f"one flat {4 * (trainer.flat.numel + trainer.N_STATS)} B gradient all-reduce)"),
-                       "ranks": world, "devices": list(range(world))},
+                       "ranks": world, "backend": (a.backend if world > 1 else None), "rccl_ranks": (world if (world > 1 and a.backend == "nccl") else 0),
+                       "devices": ([(i if a.backend == "nccl" else i % torch.cuda.device_count()) for i in range(world)]),
+                       "settle_steps": a.settle_steps},
             "roofline": {"bound": "mfma", "kernel": dominant, "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / MFMA_PEAK_TFLOPS, "avg_launch_us": k_avg_s * 1e6, "launches": kn.value,
                          "algorithmic_flops_per_launch": flops_launch, "traffic": None,
@@ -414,7 +488,7 @@ def main():
             line["loss_after_run"] = loss_now
         if parity is not None:
             line["parity"] = parity
-        tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r03_traffic.json")
         if os.path.exists(tpath):
             try:
                 ent = json.load(open(tpath)).get(f"{a.mode}:{a.precision}")
@@ -423,7 +497,8 @@ def main():
                 same_launch = (rays * S == 65536) if a.mode == "render" else (rays * S >= 65536 and (rays * S) % 65536 == 0)
                 if ent and same_launch:
                     line["roofline"]["traffic"] = ent["hbm_bytes_per_launch"]
-                    line["roofline"]["traffic_source"] = "profiles/r02_traffic.json (rocprofv3 --pmc passes of this kernel, MI355X_MICROARCH.md corrections)"
+                    line["roofline"]["traffic_source"] = ("STATIC: profiles/r03_traffic.json, recorded by rocprofv3 --pmc passes of this kernel at this launch "
+                                                          "size (scripts/profile_round.sh; MI355X_MICROARCH.md corrections), not measured in this run")
             except Exception:
                 pass
         if not a.no_other_modes and world == 1 and a.mode == "render":
@@ -454,6 +529,11 @@ def main():
                     other[mode] = {"error": repr(e)}
             r.precision = a.precision
             line["other_precision_modes"] = other
+        if a.mode == "render" and world == 1 and not a.no_train_key:
+            try:
+                line["train"] = train_key(dev, a.precision, rays, S)
+            except Exception as e:   # the secondary measurement must never take the headline down
+                line["train"] = {"error": repr(e)}
         if not a.no_cpu_baseline and world == 1:
             try:
                 line["cpu_baseline"] = cpu_baseline(state, kw, a.cpu_rays, a.mode)

@@ -21,7 +21,7 @@ PREC_F16X3 = 3
 PRECISIONS = {"bf16": PREC_BF16, "bf16x3": PREC_BF16X3, "f16": PREC_F16, "f16x3": PREC_F16X3}
 UDF_TYPES = {"abs": 0, "square": 1, "sdf": 2}
 MAX_LIN = 12
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 F_NAN_SAMPLES = 1
 F_NAN_GRADERR = 2
@@ -102,6 +102,9 @@ SYMBOLS = {
     "emap_render_bwd_workspace_bytes": (C.c_int, [C.POINTER(NetConfig), C.c_int, C.POINTER(RenderParams), C.POINTER(C.c_size_t)]),
     "emap_render_bwd": (C.c_int, [C.POINTER(NetConfig), _P, C.c_int, C.POINTER(RenderParams), _P, _P, _P, _P, _P, _P, _P,
                                   C.POINTER(CompositeGrads), C.POINTER(ParamGrads), _P, C.c_size_t, _P, _P]),
+    "emap_render_bwd_absmax_offset": (C.c_int, [C.POINTER(NetConfig), C.c_int, C.POINTER(RenderParams), C.POINTER(C.c_size_t)]),
+    "emap_render_bwd_staged": (C.c_int, [C.POINTER(NetConfig), _P, C.c_int, C.POINTER(RenderParams), _P, _P, _P, _P, _P, _P, _P,
+                                         C.POINTER(CompositeGrads), C.POINTER(ParamGrads), _P, C.c_size_t, _P, _P, C.c_int]),
     "emap_sample_rays": (C.c_int, [C.POINTER(RayDataset), C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, _P, _P, C.POINTER(RayBatch), _P]),
     "emap_train_stats": (C.c_int, [_P, _P, _P, C.c_int, C.c_float, _P, _P, _P]),
     "emap_train_loss": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, _P, _P]),

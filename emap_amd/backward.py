@@ -82,12 +82,24 @@ class ParamLayout:
         return out
 
 
+_WS_MAX_ENTRIES = 8   # distinct launch shapes per cache (training batch, validation chunk, ...): far fewer in practice
+
+
 def _workspace(cache: dict, key, nbytes: int, dev) -> torch.Tensor:
+    """Cached scratch buffer for one launch shape.  The cache keeps one buffer PER KEY and never frees or moves a buffer that is
+    still big enough: a captured hipGraph (UDFRendererBlending.capture, Trainer.capture) has the device pointers of the buffers of
+    ITS shape baked in, so a render of another shape in between (validation.render_image between replays of a training graph) must
+    not evict them.  Only when more than _WS_MAX_ENTRIES shapes have been seen is the least recently used entry dropped - callers
+    that capture graphs hold their own references as well."""
+    key = (key, str(dev))
     ws = cache.get(key)
-    if ws is None or ws.numel() < nbytes or ws.device != dev:
+    if ws is None or ws.numel() < nbytes:
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        cache.clear()
-        cache[key] = ws
+        if len(cache) >= _WS_MAX_ENTRIES and key not in cache:
+            cache.pop(next(iter(cache)))
+    else:
+        cache.pop(key)          # re-insert: dict order = recency
+    cache[key] = ws
     return ws
 
 

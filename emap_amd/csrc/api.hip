@@ -459,10 +459,31 @@ int emap_render_bwd_workspace_bytes(const EmapNetConfig* cfg, int prec, const Em
     return EMAP_OK;
 }
 
+int emap_render_bwd_absmax_offset(const EmapNetConfig* cfg, int prec, const EmapRenderParams* p, size_t* offset) {
+    NetLayout L;
+    const int rc = build_layout(cfg, prec, &L);
+    if (rc) return rc;
+    if (!p || !offset) { set_error("render_bwd_absmax_offset: null pointer"); return EMAP_E_INVALID; }
+    size_t a, b, c;
+    const size_t extra = render_bwd_extra(*p, &a, &b, &c);
+    const int m = p->up_sample_steps > 0 ? p->n_importance / p->up_sample_steps : 0;
+    const int64_t S = (int64_t)p->n_samples + (int64_t)m * std::max(p->up_sample_steps, 0);
+    *offset = extra + plan_vjp(L, (int64_t)std::max(p->n_rays, 0) * S).off_absmax;
+    return EMAP_OK;
+}
+
 int emap_render_bwd(const EmapNetConfig* cfg, const void* packed, int prec, const EmapRenderParams* p, const float* rays_o,
                     const float* rays_d, const float* depth_scale, const float* z_vals, const float* udf, const float* grad3,
                     const float* sample_dist_dev, const EmapCompositeGrads* g, const EmapParamGrads* out, void* workspace,
                     size_t workspace_bytes, int32_t* err_flags, void* stream) {
+    return emap_render_bwd_staged(cfg, packed, prec, p, rays_o, rays_d, depth_scale, z_vals, udf, grad3, sample_dist_dev, g, out,
+                                  workspace, workspace_bytes, err_flags, stream, 3);
+}
+
+int emap_render_bwd_staged(const EmapNetConfig* cfg, const void* packed, int prec, const EmapRenderParams* p, const float* rays_o,
+                           const float* rays_d, const float* depth_scale, const float* z_vals, const float* udf, const float* grad3,
+                           const float* sample_dist_dev, const EmapCompositeGrads* g, const EmapParamGrads* out, void* workspace,
+                           size_t workspace_bytes, int32_t* err_flags, void* stream, int stages) {
     NetLayout L;
     int rc = build_layout(cfg, prec, &L);
     if (rc) return rc;
@@ -485,10 +506,14 @@ int emap_render_bwd(const EmapNetConfig* cfg, const void* packed, int prec, cons
     hipStream_t st = static_cast<hipStream_t>(stream);
     float* d_udf = reinterpret_cast<float*>(ws + o_du);
     float* d_grad = reinterpret_cast<float*>(ws + o_dg);
-    // render_core's tail in reverse; it also leaves max|d_udf|, max|d_grad| for the sweep's range scale
-    rc = launch_composite_bwd(rays_o, rays_d, z_vals, udf, grad3, depth_scale, N, S, sample_dist_dev, p, g, d_udf, d_grad,
-                              reinterpret_cast<float*>(ws + o_part), reinterpret_cast<uint32_t*>(vws + pl.off_absmax), st);
-    if (rc) return rc;
+    if ((stages & 3) == 0) { set_error("render_bwd_staged: stages must have bit 0 and / or bit 1 set"); return EMAP_E_INVALID; }
+    if (stages & 1) {
+        // render_core's tail in reverse; it also leaves max|d_udf|, max|d_grad| for the sweep's range scale
+        rc = launch_composite_bwd(rays_o, rays_d, z_vals, udf, grad3, depth_scale, N, S, sample_dist_dev, p, g, d_udf, d_grad,
+                                  reinterpret_cast<float*>(ws + o_part), reinterpret_cast<uint32_t*>(vws + pl.off_absmax), st);
+        if (rc) return rc;
+    }
+    if (!(stages & 2)) return EMAP_OK;
     PointSource fin;
     memset(&fin, 0, sizeof(fin));
     fin.rays_o = rays_o; fin.rays_d = rays_d; fin.z = z_vals; fin.n_per_ray = S; fin.mid = 1; fin.sample_dist = sample_dist_dev;

@@ -137,7 +137,7 @@ class Trainer:
             # capturable: the step counters live on the device, so a whole step can be captured in a hipGraph (capture())
             self.optimizer = torch.optim.Adam([{"params": [self.p_geo], "lr": lr_geo}, {"params": [self.p_sc]}], lr=lr,
                                               **({"fused": True, "capturable": True} if fused_adam else {}))
-        self.collectives_per_step = 0 if _world(group) == 1 else (2 if eikonal_sync == "exact" else 1)
+        self.collectives_per_step = 0 if _world(group) == 1 else (3 if eikonal_sync == "exact" else 1)
         # "local": every rank normalises by its own mask sums, so the sum over ranks needs the 1/world of a mean of means
         k = 1.0 / _world(group) if eikonal_sync == "local" else 1.0
         self._igr = torch.tensor([self.igr_weight * k], device=dev)
@@ -167,41 +167,108 @@ class Trainer:
                                                  float(g0["betas"][0]), float(g0["betas"][1]), float(g0["eps"]), _lib.stream_ptr(dev)),
                        "adam_step")
 
-    def _step_native(self, rays: Dict, true_edge: torch.Tensor, n_rays_global: Optional[int]):
+    # The native step is written as four device phases separated by the (at most three) collectives, so that it can run eagerly, be
+    # captured whole in one hipGraph (one rank) or be captured phase by phase with the collectives launched between the replays
+    # (any backend, also gloo whose collectives are host code): capture(segmented=True).
+    def _ph_forward(self, S, rays, true_edge, n_rays_global):
         from . import _lib
         L = _lib.lib()
         world = _world(self.group)
         call, v, edge, scalars = self._forward(rays)
         dev = edge.device
         n_local = edge.numel()
-        n_glob = n_rays_global if n_rays_global is not None else n_local * world
+        S.update(call=call, v=v, scalars=scalars, dev=dev, world=world, n_local=n_local,
+                 n_glob=n_rays_global if n_rays_global is not None else n_local * world)
         te = true_edge.reshape(-1).to(torch.float32).contiguous()
         assert te.numel() == n_local
-        d_edge = torch.empty(n_local, device=dev)
-        stats = self._stats
+        S["d_edge"] = torch.empty(n_local, device=dev)
         with torch.cuda.device(dev):
-            st = _lib.stream_ptr(dev)
-            _lib.check(L.emap_train_stats(_lib.ptr(edge), _lib.ptr(te), _lib.ptr(scalars), n_local, 2.0 * self.edge_weight / n_glob,
-                                          _lib.ptr(d_edge), _lib.ptr(stats), st), "train_stats")
-            sc_glob = scalars
-            if world > 1 and self.eikonal_sync == "exact":
-                dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=self.group)
-                sc_glob = scalars.clone()
-                sc_glob[4], sc_glob[6] = stats[0], stats[1]
-            g = self.flat.grad
-            self._backward(call, v, d_edge, sc_glob, g[:self.flat.numel])
-            if world > 1:
-                if self.eikonal_sync == "local":
-                    g[self.flat.numel:self.flat.numel + 5] = stats      # the statistics ride in the bucket's tail
-                dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
-                if self.eikonal_sync == "local":
-                    stats = g[self.flat.numel:self.flat.numel + 5]
-            self.optimizer.step()
-            self.r.udf_network.invalidate_packed()   # the flat update does not bump the per-parameter version counters
-            out = torch.empty(2, device=dev)         # a fresh tensor per step: callers keep what step() returned
-            _lib.check(L.emap_train_loss(_lib.ptr(stats), self.edge_weight / n_glob, self.igr_weight, self.igr_ns_weight, _lib.ptr(out), st),
-                       "train_loss")
+            _lib.check(L.emap_train_stats(_lib.ptr(edge), _lib.ptr(te), _lib.ptr(scalars), n_local, 2.0 * self.edge_weight / S["n_glob"],
+                                          _lib.ptr(S["d_edge"]), _lib.ptr(self._stats), _lib.stream_ptr(dev)), "train_stats")
+        S["stats"] = self._stats
+
+    def _ph_composite_bwd(self, S):
+        sc_glob = S["scalars"]
+        if S["world"] > 1 and self.eikonal_sync == "exact":      # self._stats now holds the GLOBAL sums
+            sc_glob = S["scalars"].clone()
+            sc_glob[4], sc_glob[6] = self._stats[0], self._stats[1]
+        S["sc_glob"] = sc_glob
+        g = self.flat.grad
+        both = not (S["world"] > 1 and self.eikonal_sync == "exact")
+        self.r.backward_into(S["call"], S["v"], S["d_edge"], None, self._igr, self._igr_ns if self.igr_ns_weight != 0.0 else None,
+                             flat=g[:self.flat.numel], scalars=sc_glob, stages=3 if both else 1)
+        S["staged"] = not both
+
+    def _ph_mlp_bwd(self, S):
+        g = self.flat.grad
+        if S["staged"]:
+            self.r.backward_into(S["call"], S["v"], S["d_edge"], None, self._igr, self._igr_ns if self.igr_ns_weight != 0.0 else None,
+                                 flat=g[:self.flat.numel], scalars=S["sc_glob"], stages=2)
+        if S["world"] > 1 and self.eikonal_sync == "local":
+            g[self.flat.numel:self.flat.numel + 5] = self._stats      # the statistics ride in the bucket's tail
+
+    def _ph_update(self, S):
+        from . import _lib
+        L = _lib.lib()
+        dev = S["dev"]
+        stats = self._stats
+        if S["world"] > 1 and self.eikonal_sync == "local":
+            stats = self.flat.grad[self.flat.numel:self.flat.numel + 5]
+        frozen = self._frozen_scalars()
+        if frozen:
+            keep = self.flat.data[frozen].clone()
+        self.optimizer.step()
+        if frozen:       # torch.optim.Adam skips a parameter without gradient (runner_udf.py:150-154: variance frozen until set_trainable)
+            self.flat.data[frozen] = keep
+            self._m[frozen] = 0.0
+            self._v[frozen] = 0.0
+        self.r.udf_network.invalidate_packed()   # the flat update does not bump the per-parameter version counters
+        out = torch.empty(2, device=dev)         # a fresh tensor per step: callers keep what step() returned
+        with torch.cuda.device(dev):
+            _lib.check(L.emap_train_loss(_lib.ptr(stats), self.edge_weight / S["n_glob"], self.igr_weight, self.igr_ns_weight, _lib.ptr(out),
+                                         _lib.stream_ptr(dev)), "train_loss")
         self.last_stats = out
+        return out
+
+    def _frozen_scalars(self):
+        """Flat indices of variance / beta / gamma entries whose parameter has requires_grad=False; a frozen NETWORK tensor raises
+        (no EMAP configuration freezes one, and the fused update has no per-tensor skip)."""
+        for p in self.geo:
+            if not p.requires_grad:
+                raise NotImplementedError("Trainer: a UDF network parameter with requires_grad=False is not supported")
+        idx = []
+        for p in self.scalars:
+            if not p.requires_grad:
+                o = self.flat.offsets[id(p)]
+                idx += list(range(o, o + p.numel()))
+        return idx
+
+    def _collectives(self):
+        """The collectives of one step, in order, as (after_phase, callable): exact = [global eikonal mask sums + MSE sum (20 B),
+        the two range maxima of the MLP backward (8 B, MAX), the flat gradient]; local = [the flat gradient with the statistics in
+        its tail].  The maxima exchange makes every rank's backward use the SAME fp16 range scale, so the step does not depend on
+        how the rays are sharded (beyond the order of the floating-point sums)."""
+        if _world(self.group) == 1:
+            return []
+        ar = lambda t, op: (lambda S: dist.all_reduce(t(S), op=op, group=self.group))
+        grad = ar(lambda S: self.flat.grad, dist.ReduceOp.SUM)
+        if self.eikonal_sync == "local":
+            return [(2, grad)]
+        return [(0, ar(lambda S: self._stats, dist.ReduceOp.SUM)),
+                (1, ar(lambda S: self.r.bwd_absmax(S["call"]), dist.ReduceOp.MAX)),
+                (2, grad)]
+
+    def _step_native(self, rays: Dict, true_edge: torch.Tensor, n_rays_global: Optional[int]):
+        S = {}
+        coll = self._collectives()
+        phases = [lambda: self._ph_forward(S, rays, true_edge, n_rays_global), lambda: self._ph_composite_bwd(S),
+                  lambda: self._ph_mlp_bwd(S), lambda: self._ph_update(S)]
+        out = None
+        for i, ph in enumerate(phases):
+            out = ph()
+            for after, fn in coll:
+                if after == i:
+                    fn(S)
         return out
 
     def step(self, rays: Dict, true_edge: torch.Tensor, n_rays_global: Optional[int] = None):
@@ -239,11 +306,24 @@ class Trainer:
         return self.last_stats
 
 
-    def capture(self, rays: Dict, true_edge: torch.Tensor, n_rays_global: Optional[int] = None, warmup: int = 3):
+    def capture(self, rays: Dict, true_edge: torch.Tensor, n_rays_global: Optional[int] = None, warmup: int = 3,
+                segmented: Optional[bool] = None):
         """Capture one whole step (pack -> render forward -> statistics -> HIP backward -> [all-reduce] -> Adam) for this batch
-        shape in a hipGraph and return ``replay(rays=None, true_edge=None) -> [loss, edge_loss]`` (device tensor, static).
-        New rays / targets are copied into the graph's static buffers before the replay.  `warmup` real steps are taken first
-        (workspaces, function attributes, Adam state must exist before capturing)."""
+        shape and return ``replay(rays=None, true_edge=None) -> [loss, edge_loss]`` (device tensor, static).  New rays / targets
+        are copied into the static buffers before the replay.  `warmup` real steps are taken first (workspaces, function
+        attributes, Adam state must exist before capturing).
+
+        One rank: ONE hipGraph.  Several ranks (`segmented`, default then): one hipGraph per device phase and the collectives
+        launched between the replays - nothing about the transport is assumed (works with RCCL and with gloo, whose collectives
+        are host code and cannot be captured); `segmented=False` puts the collectives inside one graph (RCCL only)."""
+        if not self.native_tail:
+            segmented = False if segmented is None else segmented
+        world = _world(self.group)
+        if segmented is None:
+            segmented = world > 1
+        if rays.get("t_rand") is None and (rays.get("perturb_overwrite", -1) != 0) and self.r.perturb > 0:
+            raise ValueError("Trainer.capture: pass rays['t_rand'] explicitly (the reference's CPU-generator jitter draw plus its "
+                             "host-to-device copy cannot be part of a device graph)")
         dev = self.flat.data.device
         static = {k: (v.detach().clone() if isinstance(v, torch.Tensor) else v) for k, v in rays.items()}
         te = true_edge.detach().clone()
@@ -253,9 +333,29 @@ class Trainer:
             for _ in range(max(warmup, 1)):
                 self.step(static, te, n_rays_global)
         torch.cuda.current_stream(dev).wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            out = self.step(static, te, n_rays_global)
+        if not segmented:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self.step(static, te, n_rays_global)
+            graphs, coll, S = [graph], [], None
+        else:
+            S = {}
+            coll = self._collectives()
+            phases = [lambda: self._ph_forward(S, static, te, n_rays_global), lambda: self._ph_composite_bwd(S),
+                      lambda: self._ph_mlp_bwd(S), lambda: self._ph_update(S)]
+            graphs, out = [], None
+            pool = None
+            for i, ph in enumerate(phases):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool):
+                    out = ph()
+                pool = g.pool()
+                graphs.append(g)
+                g.replay()                  # capture does not execute: run the phase now, so that this pass is one real step and
+                for after, fn in coll:      # the next phase is captured on real data
+                    if after == i:
+                        fn(S)
+        keep = self.r.live_buffers()
 
         def replay(rays: Optional[Dict] = None, true_edge: Optional[torch.Tensor] = None):
             if rays is not None:
@@ -264,10 +364,17 @@ class Trainer:
                         static[k].copy_(v)
             if true_edge is not None:
                 te.copy_(true_edge)
-            graph.replay()
+            for i, g in enumerate(graphs):
+                g.replay()
+                for after, fn in coll:
+                    if after == i:
+                        fn(S)
             return out
 
-        replay.graph = graph
+        replay.graph = graphs[0] if len(graphs) == 1 else None
+        replay.graphs = graphs
+        replay.segmented = bool(segmented)
+        replay._keep = keep
         return replay
 
 

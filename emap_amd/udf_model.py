@@ -114,7 +114,9 @@ class UDFNetwork(nn.Module):
         _lib.require_cuda(vs[0], "UDFNetwork parameters")
         # version counters catch optimizer steps / in-place ops; the data pointers catch re-assigned .data; edits made through
         # `.data` in place bump neither - call invalidate_packed() after those
-        key = (prec, vs[0].device, tuple(int(t._version) for t in gs + vs + bs), tuple(t.data_ptr() for t in gs + vs + bs))
+        # (without weight_norm the g's are temporaries synthesised by _gvb: only v and b identify the state)
+        ident = (gs if self.weight_norm else []) + vs + bs
+        key = (prec, vs[0].device, tuple(int(t._version) for t in ident), tuple(t.data_ptr() for t in ident))
         hit = self._pack_cache.get(prec)
         if hit is not None and hit[0] == key:
             return hit[1]
@@ -136,8 +138,9 @@ class UDFNetwork(nn.Module):
         return buf
 
     def invalidate_packed(self):
-        """Force a re-pack on the next call (after editing parameters through ``.data`` in place)."""
-        self._pack_cache = {}
+        """Force a re-pack on the next call (after editing parameters through ``.data`` in place).  The packed buffers are KEPT and
+        re-packed in place: a captured hipGraph (RenderGraph, Trainer.capture) has their addresses baked in."""
+        self._pack_cache = {prec: (None, buf) for prec, (_, buf) in self._pack_cache.items()}
 
     def err_word(self, dev):
         if self._err is None or self._err.device != dev:

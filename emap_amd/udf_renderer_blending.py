@@ -63,6 +63,7 @@ class UDFRendererBlending:
         self.device = device
         self.precision = precision  # None -> udf_network.precision
         self._ws = {}
+        self._ws_pool = {}
         self._bws = {}
         self._err = None
         self._lay = None
@@ -128,7 +129,9 @@ class UDFRendererBlending:
             if nf is None:
                 nf = (torch.full((N,), float(near), device=dev, dtype=torch.float32),
                       torch.full((N,), float(far), device=dev, dtype=torch.float32))
-                self._const = {key: nf}
+                if len(self._const) > 16:       # bounded; never replaces a live entry in place (a captured graph may point at it)
+                    self._const.pop(next(k for k in self._const if k != "_scr"))
+                self._const[key] = nf
             near_t, far_t = nf
         else:
             near_t = _lib.f32c(near.detach().to(dev)).reshape(-1).expand(N).contiguous()
@@ -174,13 +177,15 @@ class UDFRendererBlending:
         L = _lib.lib()
         cfg = net.net_config()
         with _lib.on_device(call["ro"]):
-            key = (N, dev, prec)
+            key = (N, str(dev), prec)
             ws = self._ws.get(key)
             if ws is None:
                 nb = C.c_size_t()
                 _lib.check(L.emap_render_workspace_bytes(C.byref(cfg), prec, C.byref(p), C.byref(nb)), "render_workspace_bytes")
-                ws = torch.empty(nb.value, dtype=torch.uint8, device=dev)
-                self._ws = {key: ws}
+                ws = _workspace(self._ws_pool, key, nb.value, dev)   # one buffer per launch shape, never evicted by another shape
+                if len(self._ws) >= 8:
+                    self._ws.pop(next(iter(self._ws)))
+                self._ws[key] = ws
             if self._err is None or self._err.device != dev:
                 self._err = torch.zeros(1, dtype=torch.int32, device=dev)
             co = _lib.CompositeOut()
@@ -196,11 +201,13 @@ class UDFRendererBlending:
         v["_ws"] = ws
         return v
 
-    def backward_into(self, call, v, d_edge, d_depth=None, d_ge=None, d_ge_ns=None, flat=None, scalars=None, grad_scale=1.0):
+    def backward_into(self, call, v, d_edge, d_depth=None, d_ge=None, d_ge_ns=None, flat=None, scalars=None, grad_scale=1.0,
+                      stages=3):
         """One emap_render_bwd call: parameter gradients of  sum(d_edge*edge) + sum(d_depth*depth) + d_ge*gradient_error +
         d_ge_ns*gradient_error_near_surface  into `flat` (parameters() order of the UDF network, then variance, beta,
         gamma; allocated when None).  `scalars`: the forward's scalars, or a copy with GLOBAL eikonal mask sums in [4],[6]
-        (data-parallel).  Returns flat."""
+        (data-parallel).  `stages`: 1 = compositing adjoint only, 2 = MLP backward only (after a stages=1 call with the same
+        arguments), 3 = both; between 1 and 2 a data-parallel step max-reduces `bwd_absmax(call)` over the ranks.  Returns flat."""
         N, S, dev = call["N"], call["S"], call["dev"]
         net = self.udf_network
         lay = self._layout()
@@ -221,7 +228,8 @@ class UDFRendererBlending:
         cg.d_variance = flat.data_ptr() + es * lay.offsets[id(extra[0])]
         cg.d_beta = flat.data_ptr() + es * lay.offsets[id(extra[1])]
         cg.d_gamma = flat.data_ptr() + es * lay.offsets[id(extra[2])]
-        flat[lay.offsets[id(extra[0])]:].zero_()   # second_variance / zeta / unused scalar slots (tiny)
+        if stages & 1:
+            flat[lay.offsets[id(extra[0])]:].zero_()   # second_variance / zeta / unused scalar slots (tiny)
         cg.grad_scale = float(grad_scale)
         cg.accumulate = 0
         pg, keep = lay.tables(flat)
@@ -233,11 +241,27 @@ class UDFRendererBlending:
             nb = C.c_size_t()
             _lib.check(L.emap_render_bwd_workspace_bytes(C.byref(cfg), prec, C.byref(p), C.byref(nb)), "render_bwd_workspace_bytes")
             ws = _workspace(self._bws, (N, S, prec), nb.value, dev)
-            _lib.check(L.emap_render_bwd(C.byref(cfg), _lib.ptr(net.packed(call["prec_name"])), prec, C.byref(p), _lib.ptr(call["ro"]),
-                                         _lib.ptr(call["rd"]), _lib.ptr(call["ds"]), _lib.ptr(v["z_vals"]), _lib.ptr(v["udf"]),
-                                         _lib.ptr(v["gradients"]), _lib.ptr(v["_ws"]), C.byref(cg), C.byref(pg), _lib.ptr(ws),
-                                         ws.numel(), _lib.ptr(self._err), _lib.stream_ptr(dev)), "render_bwd")
+            _lib.check(L.emap_render_bwd_staged(C.byref(cfg), _lib.ptr(net.packed(call["prec_name"])), prec, C.byref(p),
+                                                _lib.ptr(call["ro"]), _lib.ptr(call["rd"]), _lib.ptr(call["ds"]), _lib.ptr(v["z_vals"]),
+                                                _lib.ptr(v["udf"]), _lib.ptr(v["gradients"]), _lib.ptr(v["_ws"]), C.byref(cg), C.byref(pg),
+                                                _lib.ptr(ws), ws.numel(), _lib.ptr(self._err), _lib.stream_ptr(dev), int(stages)),
+                       "render_bwd")
         return flat
+
+    def bwd_absmax(self, call):
+        """The two floats [max|dL/dudf|, max|dL/dgrad|] a stages=1 backward_into() left in the backward workspace, as a float32
+        view of that workspace: what a data-parallel step max-reduces over its ranks before the stages=2 call, so that every rank's
+        MLP backward uses the same fp16 range scale (emap_hip.h: emap_render_bwd_staged)."""
+        N, S, dev = call["N"], call["S"], call["dev"]
+        prec = _lib.PRECISIONS[call["prec_name"]]
+        cfg = self.udf_network.net_config()
+        p = call["p"]
+        L = _lib.lib()
+        nb, off = C.c_size_t(), C.c_size_t()
+        _lib.check(L.emap_render_bwd_workspace_bytes(C.byref(cfg), prec, C.byref(p), C.byref(nb)), "render_bwd_workspace_bytes")
+        _lib.check(L.emap_render_bwd_absmax_offset(C.byref(cfg), prec, C.byref(p), C.byref(off)), "render_bwd_absmax_offset")
+        ws = _workspace(self._bws, (N, S, prec), nb.value, dev)
+        return ws[off.value:off.value + 8].view(torch.float32)
 
     def _trainable(self):
         ps = list(self.udf_network.parameters()) + [self.deviation_network.variance, self.beta_network.beta, self.beta_network.gamma]
@@ -300,6 +324,15 @@ class UDFRendererBlending:
         return RenderGraph(self, rays_o, rays_d, near, far, depth_scale, cos_anneal_ratio, background_rgb, flip_saturation, t_rand,
                            reduced)
 
+    def live_buffers(self):
+        """Strong references to every cached device buffer the launch chain may currently point at (workspaces, near/far constants,
+        reduced-mode scratch, error word, packed weights, scratch of the UDF network): a captured graph keeps this list."""
+        net = self.udf_network
+        keep = [list(self._ws.values()), list(self._ws_pool.values()), list(self._bws.values()), self._err,
+                [v for k, v in self._const.items() if k != "_scr"], list(self._const.get("_scr", {}).values()),
+                [b for _, b in net._pack_cache.values()], list(net._vjp_ws.values()), list(net._scratch.values()), net._err]
+        return keep
+
     def render_reduced(self, rays_o, rays_d, near, far, depth_scale, cos_anneal_ratio=None, perturb_overwrite=-1,
                        background_rgb=None, flip_saturation=0, t_rand=None):
         """Inference-only render that writes just the per-ray results (edge, depth, normals, weight_sum): the launch mode of
@@ -350,6 +383,7 @@ class RenderGraph:
         self.graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(self.graph):
             self.out = self._run()
+        self._keep = r.live_buffers()   # the graph has these device pointers baked in: they live as long as the graph does
 
     def _run(self):
         r = self.r

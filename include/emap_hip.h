@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EMAP_ABI_VERSION 3
+#define EMAP_ABI_VERSION 4
 
 /* error codes */
 #define EMAP_OK 0
@@ -240,6 +240,18 @@ int emap_render_bwd(const EmapNetConfig* cfg, const void* packed, int prec, cons
                     const float* rays_d, const float* depth_scale, const float* z_vals, const float* udf, const float* grad3,
                     const float* sample_dist_dev, const EmapCompositeGrads* g, const EmapParamGrads* out, void* workspace,
                     size_t workspace_bytes, int32_t* err_flags, void* stream);
+/* The same call in two stages, for a data-parallel step whose ranks must agree on the fp16 range scale of the MLP backward
+ * (the scale is a power of two taken from max|dL/dudf|, max|dL/dgrad| over the launch; with rank-local maxima the step would
+ * depend on how the rays are sharded - the loop being sharded is src/runner/runner_udf.py:90-168):
+ *   stages & 1 : the compositing adjoint; leaves dL/dudf, dL/dgrad3 and the two maxima (two floats >= 0) in the workspace
+ *   stages & 2 : MLP double backward + weight gradients, reading the maxima found in the workspace
+ * Between the stages the caller may max-reduce the two floats at byte offset emap_render_bwd_absmax_offset() of the
+ * workspace across ranks (stream order is the only synchronisation needed).  stages == 3 is emap_render_bwd. */
+int emap_render_bwd_absmax_offset(const EmapNetConfig* cfg, int prec, const EmapRenderParams* p, size_t* offset);
+int emap_render_bwd_staged(const EmapNetConfig* cfg, const void* packed, int prec, const EmapRenderParams* p, const float* rays_o,
+                           const float* rays_d, const float* depth_scale, const float* z_vals, const float* udf, const float* grad3,
+                           const float* sample_dist_dev, const EmapCompositeGrads* g, const EmapParamGrads* out, void* workspace,
+                           size_t workspace_bytes, int32_t* err_flags, void* stream, int stages);
 
 /* ---- on-device ray / pixel sampler (SURVEY par. 8 f3) ---------------------------------------------
  * Replaces Dataset.gen_random_rays_patches_at (src/dataset/dataset.py:222-307): pixel draw (uniform, or 50 % uniform + 50 %
