@@ -4,7 +4,10 @@
 
 registers ``src.models.udf_model``, ``src.models.udf_renderer_blending``, ``src.models.embedder`` and
 ``src.models.loss`` in ``sys.modules`` as aliases of the emap_amd modules of the same names, so
-``runner_base.py:9-13``'s imports resolve to the HIP-backed classes.  See INTEGRATION.md.
+``runner_base.py:9-13``'s imports resolve to the HIP-backed classes.  Where the reference's other modules can be imported
+it also re-routes the two callers either side of the path: ``Dataset.gen_random_rays_patches_at`` (on-device ray sampler,
+SURVEY f3) and - once ``src.runner.runner_udf`` is imported, call ``install()`` again or ``patch_runner()`` - the
+validation loop (reduced-output renders).  See INTEGRATION.md.
 """
 import importlib
 import sys
@@ -14,6 +17,62 @@ _ALIASES = {"src.models.udf_model": "emap_amd.udf_model",
             "src.models.udf_renderer_blending": "emap_amd.udf_renderer_blending",
             "src.models.embedder": "emap_amd.embedder",
             "src.models.loss": "emap_amd.loss"}
+
+
+def dataset_method(sampler_cls=None):
+    """Replacement for ``Dataset.gen_random_rays_patches_at`` (src/dataset/dataset.py:222-307): the first call uploads the dataset's
+    edge maps / intrinsics / poses once (``DeviceRaySampler``), every call is then ONE kernel launch and no host->device copy.
+    Returns the reference's dict (rays{rays_o, rays_v, edge}, pose, intrinsics, rays_ndc_uv, rays_norm_XYZ_cam, depth_scale)."""
+    def gen_random_rays_patches_at(self, img_idx, batch_size, importance_sample=False):
+        s = getattr(self, "_emap_sampler", None)
+        if s is None:
+            cls = sampler_cls
+            if cls is None:
+                from .ray_sampler import DeviceRaySampler as cls
+            s = cls(self.edges, self.intrinsics_all, self.pose_all, device=self.device, seed=getattr(self, "emap_seed", 0))
+            self._emap_sampler = s
+        # the reference takes the importance branch only when the dataset has masks (:236-238)
+        smp = s.gen_random_rays_patches_at(int(img_idx), batch_size, importance_sample=bool(importance_sample and self.masks is not None))
+        return {"rays": {k: smp["rays"][k] for k in ("rays_o", "rays_v", "edge")}, "pose": self.pose_all[int(img_idx)],
+                "intrinsics": self.intrinsics_all[int(img_idx)], "rays_ndc_uv": smp["rays_ndc_uv"],
+                "rays_norm_XYZ_cam": smp["rays_norm_XYZ_cam"], "depth_scale": smp["depth_scale"]}
+    return gen_random_rays_patches_at
+
+
+def validate_wrapper(orig_validate):
+    """``Runner_UDF.validate`` (src/runner/runner_udf.py:287-484) consumes per-ray results only - ``edge``, ``depth`` and
+    sum_s gradients_flip * weights (:333-407).  The wrapper runs it without autograd and with the renderer in its reduced-output
+    launch mode (28 B per ray instead of 48 B per sample, ``UDFRendererBlending.inference_reduced``)."""
+    import torch
+
+    def validate(self, *a, **k):
+        r = self.renderer
+        old = getattr(r, "inference_reduced", False)
+        r.inference_reduced = True
+        try:
+            with torch.no_grad():
+                return orig_validate(self, *a, **k)
+        finally:
+            r.inference_reduced = old
+    validate.__wrapped__ = orig_validate
+    return validate
+
+
+def _patch_dataset():
+    try:   # needs cv2 & co: present where the reference runs, absent in the build image
+        ds = importlib.import_module("src.dataset.dataset")
+    except Exception:
+        return False
+    ds.Dataset.gen_random_rays_patches_at = dataset_method()
+    return True
+
+
+def _patch_runner():
+    mod = sys.modules.get("src.runner.runner_udf")   # patched only if the caller has it imported (it imports src.models.* itself)
+    if mod is None or not hasattr(mod, "Runner_UDF") or hasattr(mod.Runner_UDF.validate, "__wrapped__"):
+        return False
+    mod.Runner_UDF.validate = validate_wrapper(mod.Runner_UDF.validate)
+    return True
 
 
 def install(force: bool = True):
@@ -30,6 +89,8 @@ def install(force: bool = True):
             mod = importlib.import_module(real)
             sys.modules[alias] = mod
             setattr(sys.modules["src.models"], alias.rsplit(".", 1)[1], mod)
+    _patch_dataset()
+    _patch_runner()
     # extraction queries (SURVEY par. 8 f2): the reference module keeps its other functions; only the two query routines
     # are replaced, and only if the module can be imported at all (it needs nothing but torch)
     try:
@@ -41,3 +102,8 @@ def install(force: bool = True):
         ep.get_udf_normals_grid = extraction.get_udf_normals_grid
         ep.get_udf_normals_slow = extraction.get_udf_normals_slow
     return sorted(_ALIASES)
+
+
+def patch_runner():
+    """Call after ``from src.runner.runner_udf import Runner_UDF``: wraps ``Runner_UDF.validate`` (see validate_wrapper)."""
+    return _patch_runner()

@@ -62,6 +62,7 @@ class UDFRendererBlending:
         self.near_surface = near_surface
         self.device = device
         self.precision = precision  # None -> udf_network.precision
+        self.inference_reduced = False   # True: render() without autograd returns per-ray results only (_render_reduced_compat)
         self._ws = {}
         self._ws_pool = {}
         self._bws = {}
@@ -273,6 +274,9 @@ class UDFRendererBlending:
         """reference udf_renderer_blending.py:679-800.  Extra keyword `t_rand` ((N,1) in [-0.5,0.5)) injects
         the jitter draw (tests); otherwise it is drawn exactly like the reference: torch.rand([N,1]) on the
         CPU generator (:719)."""
+        if self.inference_reduced and not self._trainable():
+            return self._render_reduced_compat(rays_o, rays_d, near, far, depth_scale, cos_anneal_ratio, perturb_overwrite,
+                                               background_rgb, flip_saturation, t_rand)
         call = self._prepare(rays_o, rays_d, near, far, depth_scale, cos_anneal_ratio, perturb_overwrite, background_rgb,
                              flip_saturation, t_rand)
         N, S, dev = call["N"], call["S"], call["dev"]
@@ -316,6 +320,23 @@ class UDFRendererBlending:
             "z_vals": v["z_vals"].view(N, S), "alpha": v["alpha"].view(N, S), "sparse_error": v["scalars"][2],
             "eikonal_sums": v["scalars"][3:7],
         }
+
+    def _render_reduced_compat(self, rays_o, rays_d, near, far, depth_scale, cos_anneal_ratio, perturb_overwrite, background_rgb,
+                               flip_saturation, t_rand):
+        """render() for a caller that consumes per-ray results only - the validation loop, runner_udf.py:333-407: ``edge``, ``depth``
+        and  sum_s gradients_flip[:, s] * weights[:, s]  - served by the reduced-output launch mode (no per-sample tensor leaves the
+        GPU kernels).  The two per-sample entries the loop multiplies are returned as broadcast stand-ins whose product sums to the
+        rendered normal: gradients_flip = normals (N,1,3), weights = 1/S (N,S) (zero-stride views, no memory).  Selected by
+        ``self.inference_reduced`` (emap_amd.dropin.validate_wrapper sets it around Runner_UDF.validate); only without autograd."""
+        o = self.render_reduced(rays_o, rays_d, near, far, depth_scale, cos_anneal_ratio, perturb_overwrite, background_rgb,
+                                flip_saturation, t_rand)
+        N, S = o["edge"].shape[0], self.samples_per_ray
+        dev = o["edge"].device
+        ones = torch.ones(1, 1, device=dev)
+        return {"edge": o["edge"], "depth": o["depth"], "weight_sum": o["weight_sum"], "weight_sum_fg_bg": o["weight_sum"],
+                "normals": o["normals"], "gradient_error": o["gradient_error"], "sparse_error": o["sparse_error"],
+                "gradients_flip": o["normals"].view(N, 1, 3), "gradients": None,
+                "weights": (ones / S).expand(N, S), "inside_sphere": ones.expand(N, S), "reduced": True}
 
     def capture(self, rays_o, rays_d, near, far, depth_scale, cos_anneal_ratio=None, background_rgb=None, flip_saturation=0,
                 t_rand=None, reduced=False):

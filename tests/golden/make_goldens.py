@@ -360,9 +360,67 @@ def g10_extraction():
     save("g10_extraction", **out)
 
 
+def g11_rays():
+    """Ray generation of the training loop (SURVEY par. 8 f3): the reference's own Dataset.gen_random_rays_patches_at
+    (src/dataset/dataset.py:222-307), called UNBOUND on a plain namespace that carries the attributes the method reads.  The dataset
+    module imports cv2 at the top (absent here); none of the executed lines uses it, so an empty stub module is registered for the
+    import only.  The pixel draws (torch.randint, random.choices) are replaced by fixed pixels, which are recorded as inputs; the
+    edge-weighted draw is pinned separately by the class histogram of 2^18 real random.choices draws (python's own generator,
+    seeded) over the probabilities the method builds (:236-242)."""
+    import random
+    import types
+    sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+    from src.dataset.dataset import Dataset  # reference
+    meta, edges = synthetic.make_scene(n_images=3, H=40, W=50, seed=5)
+    K = torch.stack([torch.tensor(f["intrinsics"], dtype=torch.float32) for f in meta["frames"]])
+    P = torch.stack([torch.tensor(f["camtoworld"], dtype=torch.float32) for f in meta["frames"]])
+    H, W = int(meta["height"]), int(meta["width"])
+    e = torch.from_numpy(edges).float()
+    if e.dim() == 3:
+        e = e[..., None]
+    ns = types.SimpleNamespace(edges=e, masks=torch.ones(3, H, W, 3), intrinsics_all=K, intrinsics_all_inv=torch.inverse(K), pose_all=P,
+                               H=H, W=W, image_pixels=H * W, device=torch.device("cpu"))
+    gen = torch.Generator().manual_seed(17)
+    out = dict(H=np.array(H), W=np.array(W), edges=e[..., 0], intrinsics=K, pose=P)
+    orig_randint, orig_choices = torch.randint, random.choices
+
+    def run(tag, img_idx, n, importance):
+        px = torch.randint(0, W, [n], generator=gen)
+        py = torch.randint(0, H, [n], generator=gen)
+        half = n // 2
+        q = [px[:half] if importance else px, py[:half] if importance else py]
+        torch.randint = lambda low=0, high=None, size=None, **k: q.pop(0)
+        # p_valid is the row-major pixel list (all masks >= 0): index = y * W + x
+        random.choices = lambda population, weights=None, k=None: [int(py[half + i]) * W + int(px[half + i]) for i in range(n - half)]
+        try:
+            smp = Dataset.gen_random_rays_patches_at(ns, img_idx, n, importance_sample=importance)
+        finally:
+            torch.randint, random.choices = orig_randint, orig_choices
+        out.update({f"{tag}.img_idx": np.array(img_idx), f"{tag}.px": px, f"{tag}.py": py, f"{tag}.rays_o": smp["rays"]["rays_o"],
+                    f"{tag}.rays_v": smp["rays"]["rays_v"], f"{tag}.edge": smp["rays"]["edge"], f"{tag}.uv": smp["rays_ndc_uv"],
+                    f"{tag}.p": smp["rays_norm_XYZ_cam"], f"{tag}.depth_scale": smp["depth_scale"], f"{tag}.pose": smp["pose"],
+                    f"{tag}.intrinsics_out": smp["intrinsics"]})
+        out[f"{tag}.keys"] = np.array(sorted(smp.keys()) + ["rays." + k for k in sorted(smp["rays"].keys())])
+
+    run("uniform", 1, 96, False)
+    run("importance", 2, 64, True)
+    # the edge-weighted half of the draw: class histogram of real random.choices draws over the method's probabilities
+    img = e[2, ..., 0].numpy()
+    dens = np.mean(img)
+    prob = np.ones_like(img) * dens
+    prob[img > 0.1] = 1.0 - dens
+    random.seed(123)
+    idx = np.array(random.choices(np.arange(H * W), prob.reshape(-1), k=1 << 18))
+    is_edge = (img.reshape(-1) > 0.1)
+    out.update(choices_img=np.array(2), choices_k=np.array(1 << 18), choices_edge_draws=np.array(int(is_edge[idx].sum())),
+               choices_n_edge=np.array(int(is_edge.sum())), choices_density=np.array(dens, dtype=np.float64),
+               choices_counts_head=np.bincount(idx, minlength=H * W)[:256])
+    save("g11_rays", **out)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     for fn in (g1_pe, g2_mlp, g3_sample_pdf, g4_upsample_step, g5_render, g6_training, g7_perturb, g8_scalars, g9_seeded_init,
-               g10_extraction):
+               g10_extraction, g11_rays):
         if not only or fn.__name__ in only:
             fn()

@@ -202,3 +202,68 @@ def test_extraction_is_gpu_only():
         extraction.get_udf_normals_grid(None, None, 4, 0.1, device="cpu")
     with pytest.raises(RuntimeError):
         extraction.null_direction(torch.zeros(4, 50, 3))
+
+
+def test_dropin_reroutes_the_dataset_method_and_the_validation_loop(monkeypatch):
+    """emap_amd.dropin: an (unmodified) ``src.dataset.dataset.Dataset`` gets the on-device ray sampler behind its own method name and
+    returns the reference's dict keys (dataset.py:288-305, recorded in g11); ``Runner_UDF.validate`` runs with the renderer in its
+    reduced-output mode and without autograd.  Stand-in modules: the reference's need cv2 / pyhocon, absent in this image."""
+    import sys, types
+    import numpy as np
+    import torch
+    from emap_amd import dropin
+    from conftest import load_golden
+    g = load_golden("g11_rays")
+
+    class FakeSampler:                       # the DeviceRaySampler interface on the CPU (the kernel itself is tested in -m gpu)
+        def __init__(self, edges, K, P, device="cpu", seed=0):
+            self.args = (edges, K, P, device, seed)
+            self.calls = []
+
+        def gen_random_rays_patches_at(self, img_idx, n, importance_sample=False):
+            self.calls.append((img_idx, n, importance_sample))
+            z = lambda *sh: torch.zeros(*sh)
+            return {"rays": {"rays_o": z(n, 3), "rays_v": z(n, 3), "edge": z(n, 1)}, "rays_ndc_uv": z(n, 2), "rays_norm_XYZ_cam": z(n, 3),
+                    "depth_scale": z(n, 1), "pixels": z(n, 2), "img_idx": z(1)}
+
+    class Dataset:                           # attribute names of the reference's Dataset (dataset.py:86-135)
+        def __init__(self):
+            self.edges = torch.from_numpy(g["edges"])[..., None]
+            self.intrinsics_all, self.pose_all = torch.from_numpy(g["intrinsics"]), torch.from_numpy(g["pose"])
+            self.masks = torch.ones(3, 40, 50, 3)
+            self.device = torch.device("cpu")
+
+        def gen_random_rays_patches_at(self, img_idx, batch_size, importance_sample=False):
+            raise AssertionError("the host sampler must have been replaced")
+
+    Dataset.gen_random_rays_patches_at = dropin.dataset_method(FakeSampler)
+    ds = Dataset()
+    smp = ds.gen_random_rays_patches_at(2, 64, importance_sample=True)
+    keys = sorted(smp.keys()) + ["rays." + k for k in sorted(smp["rays"].keys())]
+    assert keys == list(g["importance.keys"])                                   # exactly the reference's sample dict
+    assert torch.equal(smp["pose"], ds.pose_all[2]) and torch.equal(smp["intrinsics"], ds.intrinsics_all[2])
+    assert ds._emap_sampler.calls == [(2, 64, True)]
+    ds.masks = None
+    ds.gen_random_rays_patches_at(0, 8, importance_sample=True)
+    assert ds._emap_sampler.calls[-1] == (0, 8, False) and len(ds._emap_sampler.calls) == 2   # one upload, :236-238's mask condition
+
+    # the validation loop: module stand-in, patched through install()
+    seen = {}
+
+    class Renderer:
+        inference_reduced = False
+
+    class Runner_UDF:
+        def __init__(self):
+            self.renderer = Renderer()
+
+        def validate(self, idx=-1):
+            seen["reduced"], seen["grad"] = self.renderer.inference_reduced, torch.is_grad_enabled()
+            return idx
+
+    mod = types.ModuleType("src.runner.runner_udf")
+    mod.Runner_UDF = Runner_UDF
+    monkeypatch.setitem(sys.modules, "src.runner.runner_udf", mod)
+    assert dropin.patch_runner() and not dropin.patch_runner()                  # wrapped once
+    r = Runner_UDF()
+    assert r.validate(idx=3) == 3 and seen == {"reduced": True, "grad": False} and r.renderer.inference_reduced is False

@@ -817,3 +817,59 @@ def test_image_render_is_chunk_invariant():
         assert rel(t(big["normals"]), torch.cat(ref_n)) <= 5e-4, perturb
     e, d, nrm = to_images(big, H, W)
     assert e.shape == (H, W) and e.dtype.name == "uint8" and d.shape == (H, W) and nrm.shape == (H, W, 3)
+
+
+def test_validation_loop_consumption_through_the_reduced_mode():
+    """What emap_amd.dropin.validate_wrapper switches on: render() with ``inference_reduced`` serves the three things Runner_UDF.validate
+    reads (edge, depth, sum_s gradients_flip * weights - runner_udf.py:333-407, restated here as the consumer) from the 28 B/ray launch
+    mode, equal to the full render's."""
+    net, _, _ = mk("d8w256L10", "f16x3")
+    r = mk_renderer(net, 64, 64, 4)
+    from emap_amd import synthetic
+    ro, rd, near, far, ds = [x.to(DEV) for x in synthetic.make_rays(512, seed=5)]
+    S = r.n_samples + r.n_importance
+    consume = lambda o: (o["edge"], o["depth"], ((o["gradients_flip"] if o.get("gradients_flip") is not None else o["gradients"])
+                                                 * o["weights"][:, :S, None]).sum(dim=1))
+    with torch.no_grad():
+        full = consume(r.render(ro, rd, near, far, ds, cos_anneal_ratio=1.0, perturb_overwrite=0))
+        r.inference_reduced = True
+        o = r.render(ro, rd, near, far, ds, cos_anneal_ratio=1.0, perturb_overwrite=0)
+        red = consume(o)
+        r.inference_reduced = False
+    assert o["reduced"] and o["inside_sphere"] is not None and o["weights"].shape == (512, S) and o["weights"].stride() == (0, 0)
+    for a, b, tol in zip(red, full, (1e-6, 1e-6, 2e-6)):
+        assert rel(a, b) <= tol
+    # with trainable parameters and autograd on, the flag is ignored (the training path needs the per-sample tensors)
+    r.inference_reduced = True
+    o2 = r.render(ro[:32], rd[:32], near[:32], far[:32], ds[:32], cos_anneal_ratio=1.0, perturb_overwrite=0)
+    assert "reduced" not in o2 and o2["weights"].shape == (32, S)
+
+
+def test_captured_graph_survives_renders_of_other_shapes():
+    """Advisor r2: a captured render graph has the device pointers of its workspaces, near/far constants and packed weights baked in;
+    a render of another batch shape (validation chunks between training-graph replays), a re-pack after a parameter update and an
+    allocator trim in between must leave them alive and in place."""
+    from emap_amd import synthetic
+    net, _, _ = mk("d8w256L10", "f16x3")
+    r = mk_renderer(net, 64, 64, 4)
+    ro, rd, near, far, ds = [x.to(DEV) for x in synthetic.make_rays(512, seed=9)]
+    tr = synthetic.make_t_rand(512, seed=3).to(DEV)
+    g = r.capture(ro, rd, 0.05, 6.0, ds, cos_anneal_ratio=1.0, t_rand=tr)
+    ref = {k: v.clone() for k, v in g().items() if isinstance(v, torch.Tensor)}
+    packed_ptr = net.packed("f16x3").data_ptr()
+    with torch.no_grad():
+        for n, nf in ((8192, (0.05, 6.0)), (100, (0.1, 5.0)), (4096, (0.05, 6.0))):      # other shapes, other near/far constants
+            o = synthetic.make_rays(n, seed=n)
+            r.render(o[0].to(DEV), o[1].to(DEV), nf[0], nf[1], o[4].to(DEV), cos_anneal_ratio=1.0, perturb_overwrite=0)
+            r.render_reduced(o[0].to(DEV), o[1].to(DEV), nf[0], nf[1], o[4].to(DEV), cos_anneal_ratio=1.0, perturb_overwrite=0)
+    net.invalidate_packed()
+    assert net.packed("f16x3").data_ptr() == packed_ptr                     # re-packed in place
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    junk = [torch.full((1 << 22,), float("nan"), device=DEV) for _ in range(64)]    # whatever was freed is overwritten now
+    del junk
+    again = g()
+    torch.cuda.synchronize()
+    r.check_errors()
+    for k, v in ref.items():
+        assert torch.equal(again[k], v), k

@@ -1,7 +1,7 @@
-"""On-device ray sampler (SURVEY par. 8 f3, emap_amd.DeviceRaySampler / emap_sample_rays) vs the reference formulas of
-Dataset.gen_random_rays_patches_at (src/dataset/dataset.py:222-307).  The reference's dataset module needs cv2 and cannot be
-imported here (SURVEY par. 8c), so the deterministic part is checked against a line-by-line torch restatement of :265-287 and
-hand-computed cases, and the random part by its distribution."""
+"""On-device ray sampler (SURVEY par. 8 f3, emap_amd.DeviceRaySampler / emap_sample_rays) vs Dataset.gen_random_rays_patches_at
+(src/dataset/dataset.py:222-307).  Pinned to the reference by tests/golden/g11_rays.npz: the reference method itself, run unbound on
+fixed pixels (make_goldens.py:g11_rays), and the class histogram of 2^18 real ``random.choices`` draws over its probabilities.  The
+line-by-line restatement of :265-287 below (used for the larger pixel sets) is itself checked against that golden."""
 import numpy as np
 import pytest
 import torch
@@ -25,6 +25,68 @@ def reference_rays(edges, K, P, img_idx, px, py):
     rays_v = torch.matmul(P[img_idx, None, :3, :3], rays_v[:, :, None]).squeeze()
     rays_o = P[img_idx, None, :3, 3].expand(rays_v.shape)
     return {"rays_o": rays_o, "rays_v": rays_v, "edge": edge, "uv": uv, "p": p, "depth_scale": depth_scale}
+
+
+def _g11():
+    from conftest import load_golden
+    return load_golden("g11_rays")
+
+
+@pytest.mark.parametrize("tag", ["uniform", "importance"])
+def test_restatement_equals_reference_golden(tag):
+    """reference_rays() above == the reference's Dataset.gen_random_rays_patches_at on the recorded pixels (bit for bit: same torch ops)."""
+    g = _g11()
+    e = torch.from_numpy(g["edges"])[..., None]
+    ref = reference_rays(e, torch.from_numpy(g["intrinsics"]), torch.from_numpy(g["pose"]), int(g[f"{tag}.img_idx"]),
+                         torch.from_numpy(g[f"{tag}.px"]), torch.from_numpy(g[f"{tag}.py"]))
+    for k, gk in (("rays_o", "rays_o"), ("rays_v", "rays_v"), ("edge", "edge"), ("uv", "uv"), ("p", "p"), ("depth_scale", "depth_scale")):
+        assert torch.equal(ref[k], torch.from_numpy(g[f"{tag}.{gk}"])), k
+    assert list(g[f"{tag}.keys"]) == ["depth_scale", "intrinsics", "pose", "rays", "rays_ndc_uv", "rays_norm_XYZ_cam", "rays.edge",
+                                      "rays.rays_o", "rays.rays_v"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["uniform", "importance"])
+def test_device_sampler_vs_reference_golden(tag):
+    """emap_sample_rays on the pixels the reference run used == the reference's recorded sample dict (g11)."""
+    g = _g11()
+    K, P = torch.from_numpy(g["intrinsics"]), torch.from_numpy(g["pose"])
+    s = emap_amd.DeviceRaySampler(torch.from_numpy(g["edges"]), K, P, device="cuda:0")
+    img = int(g[f"{tag}.img_idx"])
+    px, py = torch.from_numpy(g[f"{tag}.px"]), torch.from_numpy(g[f"{tag}.py"])
+    out = s.gen_random_rays_patches_at(img, len(px), pixels=torch.stack([px, py], -1))
+    torch.cuda.synchronize()
+    got = {"rays_o": out["rays"]["rays_o"], "rays_v": out["rays"]["rays_v"], "edge": out["rays"]["edge"], "uv": out["rays_ndc_uv"],
+           "p": out["rays_norm_XYZ_cam"], "depth_scale": out["depth_scale"], "pose": out["pose"], "intrinsics_out": out["intrinsics"]}
+    for k, v in got.items():
+        want = torch.from_numpy(g[f"{tag}.{k}"])
+        assert v.shape == want.shape, k
+        assert float((v.cpu() - want).abs().max()) <= 2e-6 * max(1.0, float(want.abs().max())), k
+    assert torch.equal(got["edge"].cpu(), torch.from_numpy(g[f"{tag}.edge"])) and torch.equal(got["rays_o"].cpu(), torch.from_numpy(g[f"{tag}.rays_o"]))
+    assert set(g[f"{tag}.keys"]) - {"rays." + k for k in out["rays"]} <= set(out.keys())     # every key the reference returns
+
+
+@pytest.mark.gpu
+def test_edge_weighted_draw_vs_reference_random_choices_histogram():
+    """The edge-weighted half of the importance draw against 2^18 draws of the reference's own ``random.choices`` (g11): the two
+    edge-class fractions are samples of the same binomial (6 sigma of the difference), and the device draw is uniform inside the class
+    like the host draw's head counts."""
+    g = _g11()
+    img = int(g["choices_img"])
+    s = emap_amd.DeviceRaySampler(torch.from_numpy(g["edges"]), torch.from_numpy(g["intrinsics"]), torch.from_numpy(g["pose"]),
+                                  device="cuda:0", seed=4)
+    k = int(g["choices_k"])
+    o = s.gen_random_rays_patches_at(img, 2 * k, importance_sample=True)
+    pix = o["pixels"].cpu()[k:]                                              # the edge-weighted half
+    is_edge = torch.from_numpy(g["edges"])[img] > 0.1
+    f_dev = float(is_edge[pix[:, 1], pix[:, 0]].float().mean())
+    f_ref = int(g["choices_edge_draws"]) / k
+    ne, d = int(g["choices_n_edge"]), float(g["choices_density"])
+    nn = is_edge.numel() - ne
+    p_edge = ne * (1 - d) / (ne * (1 - d) + nn * d)
+    sd = (p_edge * (1 - p_edge) / k) ** 0.5
+    assert abs(f_ref - p_edge) < 6 * sd                                      # the closed form the kernel implements == the host draw
+    assert abs(f_dev - f_ref) < 6 * sd * 2 ** 0.5
 
 
 def _scene(**kw):
