@@ -12,9 +12,6 @@
 // tangents <= O(1e3) on the reference networks: 2^13 * 0.5, 2^9 * 64 and 2^4 * 4e3 stay below the f16 maximum.
 // Measured (round 1): same accuracy (udf 6e-7, grad 1e-5 / 1e-6), all parity tests green, but 3 % SLOWER than the
 // two-accumulator form (the extra scaling multiplies cost more than the freed registers buy), so it is off by default.
-#ifndef EMAP_F16X3_ONE_ACC
-#define EMAP_F16X3_ONE_ACC 0
-#endif
 
 namespace emap {
 constexpr float F16X3_WS = 8192.0f;

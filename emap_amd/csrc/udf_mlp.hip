@@ -98,14 +98,8 @@ __device__ __forceinline__ void pack_body(const PackArgs& a, unsigned block) {
         if (o < Ld.out_dim && col >= 0 && col < n_in) w = rs[l * H + o] * a.v[l][(size_t)o * n_in + col] * mult;
         const __bf16 hi = (__bf16)w;
         outv[e] = (part == 0) ? hi : (__bf16)(w - (float)hi);
-#if EMAP_F16X3_ONE_ACC
-        const float ws = (NP == 2) ? w * F16X3_WS : w;                        // split-fp16: pre-scaled weights, plain lo part
-        const _Float16 hh = (_Float16)ws;
-        outh[e] = (part == 0) ? hh : (_Float16)(ws - (float)hh);
-#else
         const _Float16 hh = (_Float16)w;
         outh[e] = (part == 0) ? hh : (_Float16)((w - (float)hh) * 2048.0f);  // lo parts scaled by 2^11 (split-fp16)
-#endif
     }
     char* dst = a.packed + a.L.frag_off_bytes + F * FRAG_BYTES + lane * 16;
     if (f16) *reinterpret_cast<f16x8*>(dst) = outh;
@@ -175,14 +169,8 @@ __device__ __forceinline__ void pack_t_body(const PackArgs& a, unsigned block) {
         if (o < Ld.out_dim && col >= 0 && col < n_in) w = rs[l * H + o] * a.v[l][(size_t)o * n_in + col] * mult;
         const __bf16 hi = (__bf16)w;
         outv[e] = (part == 0) ? hi : (__bf16)(w - (float)hi);
-#if EMAP_F16X3_ONE_ACC
-        const float ws = (NP == 2) ? w * F16X3_WS : w;
-        const _Float16 hh = (_Float16)ws;
-        outh[e] = (part == 0) ? hh : (_Float16)(ws - (float)hh);
-#else
         const _Float16 hh = (_Float16)w;
         outh[e] = (part == 0) ? hh : (_Float16)((w - (float)hh) * 2048.0f);
-#endif
     }
     char* dst = a.packed + a.L.t_frag_off_bytes + F * FRAG_BYTES + lane * 16;
     if (f16) *reinterpret_cast<f16x8*>(dst) = outh;
@@ -426,27 +414,25 @@ int launch_mlp_f16x3(const NetLayout&, const void*, const PointSource&, int64_t,
 
 // kernel variant: 0 = "classic" (column-split waves, weights shared through LDS, one wave per SIMD),
 // 1 = "fs" (feature-split waves, one workgroup per CU), 2 = "fs2" (feature-split, two/three workgroups per CU),
-// 3 = "rev" (grad launches only: forward + reverse sweep on 32x32x16 MFMA tiles, udf_mlp_rev32.inc),
-// 4 = "rev16" (the same algorithm on 16x16x32 tiles, udf_mlp_rev.inc: the round-1/2 kernel, kept for same-box A/B),
-// 5 = "rev128" (variant 3 with a 128-point tile: one 8-wave workgroup per CU).
-// EMAP_MLP_KERNEL=classic|fs|fs2 forces one forward-mode variant, EMAP_GRAD_MODE=fwd|rev|rev16 picks how d(udf)/dx is
-// computed (A/B measurements).
+// 3 = "rev" (grad launches only: forward + reverse sweep on 32x32x16 MFMA tiles, udf_mlp_rev32.inc).
+// The library reads exactly two environment switches, per call: EMAP_MLP_KERNEL=classic|fs|fs2 forces one forward-mode variant,
+// EMAP_GRAD_MODE=fwd|rev picks how d(udf)/dx is computed (A/B measurements, tests); the precision mode is an API argument.
 static int mlp_variant(const NetLayout& L, int prec, int64_t P, bool grad) {
     // read on every call (two getenv, ~100 ns): the tests and the A/B scripts flip them inside one process
     const char* e = getenv("EMAP_MLP_KERNEL");
     const int forced = !e ? -1 : (!strcmp(e, "classic") ? 0 : (!strcmp(e, "fs") ? 1 : (!strcmp(e, "fs2") ? 2 : -1)));
     const char* gm = getenv("EMAP_GRAD_MODE");
-    const int grad_mode = !gm ? -1 : (!strcmp(gm, "fwd") ? 0 : (!strcmp(gm, "rev") ? 1 : (!strcmp(gm, "rev16") ? 2 : (!strcmp(gm, "rev128") ? 3 : -1))));
+    const int grad_mode = !gm ? -1 : (!strcmp(gm, "fwd") ? 0 : (!strcmp(gm, "rev") ? 1 : -1));
     // reverse mode halves the MFMA work of a grad launch but a tile is two dependent sweeps: it wins once most CUs have a
     // workgroup (measured crossover: the split modes between 8k and 12k points, single-pass modes at 16k).
     const int64_t rev_min = (prec == EMAP_PREC_F16X3 || prec == EMAP_PREC_BF16X3) ? 10240 : 16384;
-    if (grad && L.has_rev && forced < 0 && grad_mode != 0 && (P >= rev_min || grad_mode >= 1)) return grad_mode == 2 ? 4 : (grad_mode == 3 ? 5 : 3);
+    if (grad && L.has_rev && forced < 0 && grad_mode != 0 && (P >= rev_min || grad_mode >= 1)) return 3;
     if (forced >= 0) return forced;
     (void)prec; (void)P;
     return 2;   // fs2 (two or three workgroups per CU) measured fastest or equal at every size and mode on MI355X
 }
 
-bool mlp_uses_rev(const NetLayout& L, int prec, int64_t P) { return mlp_variant(L, prec, P, true) >= 3; }
+bool mlp_uses_rev(const NetLayout& L, int prec, int64_t P) { return mlp_variant(L, prec, P, true) == 3; }
 
 int launch_mlp(const NetLayout& L, const void* packed, int prec, const PointSource& src, int64_t P, float* udf,
                float* grad3, hipStream_t st, int32_t* err_flags, void* scratch) {

@@ -3,11 +3,7 @@
 namespace emap {
 int launch_mlp_f16x3(const NetLayout& L, const void* packed, const PointSource& src, int64_t P, float* udf, float* grad3,
                       hipStream_t st, int variant, int32_t* err, void* scratch) {
-#if EMAP_F16X3_ONE_ACC
-    if (variant < 2) variant = 2;   // the one-accumulator weight format is only implemented by the fs2 / reverse kernels
-#endif
-    if (variant == 3 || variant == 5) return launch_mlp_rev32_mode<EMAP_PREC_F16X3>(L, packed, src, P, udf, grad3, st, err, scratch, variant == 5);
-    if (variant == 4) return launch_mlp_rev_mode<EMAP_PREC_F16X3>(L, packed, src, P, udf, grad3, st, err, scratch);
+    if (variant == 3) return launch_mlp_rev32_mode<EMAP_PREC_F16X3>(L, packed, src, P, udf, grad3, st, err, scratch);
     if (variant == 2) return launch_mlp_fs2_mode<EMAP_PREC_F16X3>(L, packed, src, P, udf, grad3, st, err);
     if (variant == 1) return launch_mlp_fs_mode<EMAP_PREC_F16X3>(L, packed, src, P, udf, grad3, st, err);
     return launch_mlp_mode<EMAP_PREC_F16X3>(L, packed, src, P, udf, grad3, st, err);
@@ -19,9 +15,3 @@ int launch_vjp_sweep_f16x3(const NetLayout& L, const void* packed, const PointSo
                                                  absmax, ldot, st, err);
 }
 }  // namespace emap
-#ifdef EMAP_TIMELINE
-// debug builds only: copy the s_memtime stamps of the last udf_mlp_rev32 launch (f16x3) to the host
-extern "C" int emap_debug_timeline(long long* dst, int n) {
-    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(emap::emap_tl_buf), (size_t)n * sizeof(long long));
-}
-#endif

@@ -116,107 +116,18 @@ __device__ __forceinline__ void wgrad_store(const WgradArgs& a, const WgradJob& 
     }
 }
 
-template <class V8, int NB>
-__device__ __forceinline__ void wgrad_run(const WgradArgs& a, const WgradJob& J, int slice, int wave, int lane) {
-    constexpr int CT = 4 * NB;
-    const int t0 = (int)(((long long)a.n_tiles * slice) / J.n_slices), t1 = (int)(((long long)a.n_tiles * (slice + 1)) / J.n_slices);
-    const int nrt = (wave < J.z_rt ? 1 : 0) + (wave + 8 < J.z_rt ? 1 : 0);
-    f32x4 acc[2][CT];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int c = 0; c < CT; ++c) acc[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float bsum[2] = {0.f, 0.f};
-    if (nrt > 0 && t1 > t0) {
-        const size_t zts = (size_t)a.z_tile_kb * 1024, ats = (size_t)a.a_tile_kb * 1024;
-        const char* zb = wg_uniform(a.stash_z + (size_t)J.z_off * 1024 + (size_t)wave * 2048);
-        const char* ab = wg_uniform(a.stash_a + (size_t)J.a_off * 1024);
-        const int z1 = (nrt > 1) ? 8 * 2048 : 0;
-        const int voff = lane * 16;
-        constexpr int R = (CT >= 8) ? CT / 2 : CT;   // prefetch ring: fragments in flight per wave
-        V8 af[R], za[2], zb2[2];
-        auto ldz = [&](V8 (&z)[2], int tile, int s) __attribute__((always_inline)) {
-            const char* b = zb + (size_t)tile * zts + s * 1024;
-            wg_load(z[0], voff, b);
-            wg_load(z[1], voff, b + z1);
-        };
-        // NT tiles = 2*NT steps of straight-line code: prologue loads, steps that prefetch R fragments ahead, a last step that
-        // drains - no load is in flight across a loop back-edge (the compiler would otherwise be free to copy such registers).
-        // A fragment (u, c) lives in ring slot c % R (R divides CT).  Loads younger than A(u, c) when it is needed:
-        //   c == 0: R-1 (the wait also retires Z(u), issued a step earlier);  0 < c < R: R+1 (Z(u+1) was issued in between);
-        //   c >= R: R-1;  in the last step nothing is issued any more: min(R-1, CT-1-c).
-        auto block = [&](auto nt_c, int tb) __attribute__((always_inline)) {
-            constexpr int NT = decltype(nt_c)::value;
-            ldz(za, tb, 0);
-            {
-                const char* a0 = ab + (size_t)tb * ats;
-#pragma unroll
-                for (int c = 0; c < R; ++c) wg_load(af[c], voff, a0 + (c < J.a_ct ? c : J.a_ct - 1) * 2048);
-            }
-            wg_static_for<2 * NT>([&](auto u_c) __attribute__((always_inline)) {
-                constexpr int u = decltype(u_c)::value;
-                constexpr bool LAST = (u == 2 * NT - 1);
-                V8 (&zc)[2] = (u & 1) ? zb2 : za;
-                V8 (&zn)[2] = (u & 1) ? za : zb2;
-                wg_wait3<R - 1>(zc[0], zc[1], af[0]);
-                const int ntile = tb + ((u + 1) >> 1), ns = (u + 1) & 1;
-                if constexpr (!LAST) ldz(zn, ntile, ns);
-#pragma unroll
-                for (int i = 0; i < 2; ++i)   // value columns are K slots e with e % 4 < 2
-                    bsum[i] += ((float)zc[i][0] + (float)zc[i][1]) + ((float)zc[i][4] + (float)zc[i][5]);
-                const char* ac = ab + (size_t)(tb + (u >> 1)) * ats + (u & 1) * 1024;
-                const char* an = ab + (size_t)ntile * ats + ns * 1024;
-                wg_static_for<CT>([&](auto c_c) __attribute__((always_inline)) {
-                    constexpr int c = decltype(c_c)::value;
-                    constexpr int lastY = (R - 1 < CT - 1 - c) ? R - 1 : CT - 1 - c;
-                    if constexpr (c > 0) wg_wait<LAST ? lastY : (c < R ? R + 1 : R - 1)>(af[c % R]);
-                    acc[0][c] = mfma16w(zc[0], af[c % R], acc[0][c]);
-                    acc[1][c] = mfma16w(zc[1], af[c % R], acc[1][c]);
-                    constexpr int cn = (c + R) % CT;                       // the fragment R ahead: same step or the next one
-                    if constexpr (c + R < CT) wg_load(af[c % R], voff, ac + (cn < J.a_ct ? cn : J.a_ct - 1) * 2048);
-                    else if constexpr (!LAST) wg_load(af[c % R], voff, an + (cn < J.a_ct ? cn : J.a_ct - 1) * 2048);
-                });
-            });
-        };
-        int tile = t0;
-        for (; tile + 4 <= t1; tile += 4) block(std::integral_constant<int, 4>{}, tile);
-        for (; tile < t1; ++tile) block(std::integral_constant<int, 1>{}, tile);
-    }
-    wgrad_store<CT>(a, J, slice, wave, lane, acc, bsum);
-}
-
-template <class V8>
-__global__ __launch_bounds__(512, 1) void wgrad_direct_kernel(const WgradArgs a) {
-    int ji = 0;
-    while (ji + 1 < a.n_jobs && (int)blockIdx.x >= a.job[ji + 1].first_wg) ++ji;
-    const WgradJob J = a.job[ji];
-    const int slice = (int)blockIdx.x - J.first_wg;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nb = (J.a_ct + 3) >> 2;
-    if (nb <= 1) wgrad_run<V8, 1>(a, J, slice, wave, lane);
-    else if (nb == 2) wgrad_run<V8, 2>(a, J, slice, wave, lane);
-    else if (nb == 3) wgrad_run<V8, 3>(a, J, slice, wave, lane);
-    else wgrad_run<V8, 4>(a, J, slice, wave, lane);
-}
-
 // ---------------------------------------------------------------------------------------------
-// weight-gradient GEMM, operands staged through LDS by DMA (the default)
+// weight-gradient GEMM, operands staged through LDS by DMA
 // ---------------------------------------------------------------------------------------------
-// In wgrad_direct_kernel every one of the 8 waves pulls ALL column-tile fragments of a step (they share them; only the two Z
-// fragments are its own): 8 x 18 KiB per step through the CU's 64 B/clk vector-memory path = 2.3 k cycles against 1.0 k cycles
+// If every one of the 8 waves pulled ALL column-tile fragments of a step itself (round 2's first version; they share them, only
+// the two Z fragments are a wave's own): 8 x 18 KiB per step through the CU's 64 B/clk vector-memory path = 2.3 k cycles against 1.0 k cycles
 // of MFMA per SIMD - L1-bandwidth bound by 2x, and every 1 KiB load costs its wave ~50 issue cycles.  Here each fragment of a
 // step is fetched ONCE per workgroup, straight into LDS (global_load_lds_dwordx4: lane-linear 1 KiB, exactly the fragment
 // layout), 2 A + 2 Z fragments per wave and step, and read back with ds_read_b128 (256 B/clk).  Ring of NST = D + 1 stages, D
 // steps in flight (no registers are involved, so nothing the compiler could copy: loads stay in flight across the loop
 // back-edge); per step: s_waitcnt vmcnt (my fragments of this step have landed) -> s_barrier (everyone's have, and everyone
 // has finished reading the stage about to be refilled) -> issue step u + D -> 18 ds_read_b128 + 32 MFMAs.
-#ifndef EMAP_WG_ABL
-#define EMAP_WG_ABL 0
-#endif
-#ifndef WGRAD_DEPTH
-#define WGRAD_DEPTH 3     // steps (32 KiB each) in flight per workgroup; the ring has WGRAD_DEPTH + 1 stages (<= 160 KiB of LDS)
-#endif
+constexpr int WGRAD_DEPTH = 3;   // steps (32 KiB each) in flight per workgroup; the ring has WGRAD_DEPTH + 1 stages (<= 160 KiB of LDS)
 __device__ __forceinline__ void wg_dma16(unsigned lds_dst, const char* gsrc) {
     unsigned keep;   // M0 = LDS byte address of lane 0's 16 bytes; written in the statement that uses it (the compiler owns M0)
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
@@ -239,18 +150,9 @@ __device__ __forceinline__ void wgrad_lds_run(const WgradArgs& a, const WgradJob
         for (int c = 0; c < CT; ++c) acc[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
     float bsum[2] = {0.f, 0.f};
     if (nsteps > 0) {
-#if EMAP_WG_ABL == 1
-        const size_t zts = (size_t)J.z_rt * 2048, ats = (size_t)J.a_ct * 2048;
-#else
         const size_t zts = (size_t)a.z_tile_kb * 1024, ats = (size_t)a.a_tile_kb * 1024;
-#endif
-#if EMAP_WG_ABL == 1   // timing ablation (wrong data): read as if the stash were level-major, each job streaming one contiguous range
-        const char* zsrc = a.stash_z + (size_t)J.z_off * 1024 * VJP_CHUNK_TILES + lane * 16;
-        const char* asrc = a.stash_a + (size_t)J.a_off * 1024 * VJP_CHUNK_TILES + lane * 16;
-#else
         const char* zsrc = a.stash_z + (size_t)J.z_off * 1024 + lane * 16;
         const char* asrc = a.stash_a + (size_t)J.a_off * 1024 + lane * 16;
-#endif
         const unsigned lds0 = (unsigned)(size_t)smem;
         // what this wave fetches: A fragments 8i + wave (folded into the valid range: duplicates write identical bytes) and its Z rows
         int ca[NA], zr[2];
@@ -554,12 +456,6 @@ int launch_wgrad(const NetLayout& L, const VjpLayout& V, const WgradJob* jobs, i
     a.stash_a = stash_a; a.stash_z = stash_z; a.partial = partial;
     a.n_tiles = n_tiles; a.n_jobs = n_jobs; a.a_tile_kb = V.a_tile_kb; a.z_tile_kb = V.z_tile_kb; a.accumulate = accumulate;
     for (int i = 0; i < n_jobs; ++i) a.job[i] = jobs[i];
-    const char* e = getenv("EMAP_WGRAD_LDS");   // 0: every wave loads its operands itself (A/B switch, read per call)
-    if (e && atoi(e) == 0) {
-        if (L.is_f16) hipLaunchKernelGGL(wgrad_direct_kernel<f16x8>, dim3(total_wg), dim3(512), 0, st, a);
-        else hipLaunchKernelGGL(wgrad_direct_kernel<bf16x8>, dim3(total_wg), dim3(512), 0, st, a);
-        return check_launch("wgrad");
-    }
     constexpr size_t lds = (size_t)(WGRAD_DEPTH + 1) * 32 * 1024;   // NST stages of (16 A + 16 Z) KiB
     static uint64_t attr_mask = 0;
     if (attr_needed(attr_mask)) {

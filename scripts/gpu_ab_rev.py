@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Same-box A/B of the value + grad_x MLP kernels: EMAP_GRAD_MODE in {rev (32x32x16 tiles), rev16 (16x16x32 tiles), fwd}.
+"""Same-box A/B of the value + grad_x MLP kernels: EMAP_GRAD_MODE in {rev (reverse sweep, 32x32x16 tiles), fwd (forward-mode tangents)};
+EMAP_HIP_LIB selects another build of the library (scripts/build_variant.sh) for A/B of kernel changes.
 
 Interleaved rounds in ONE process (the env switch is re-read per call), HIP-event medians, and the agreement of every variant
 with the fp64 CPU oracle on the same points (sizes the oracle finishes in seconds) and with the reference golden g2.
@@ -20,7 +21,7 @@ def main():
     ap.add_argument("modes", nargs="*", default=["f16x3"])
     ap.add_argument("--points", type=int, default=65536)
     ap.add_argument("--rounds", type=int, default=15)
-    ap.add_argument("--variants", default="rev,rev16")
+    ap.add_argument("--variants", default="rev,fwd")
     ap.add_argument("--no-oracle", action="store_true")
     args = ap.parse_args()
     dev = torch.device("cuda:0")

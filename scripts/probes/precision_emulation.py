@@ -1,4 +1,4 @@
-"""CPU emulation of the split-precision arithmetic of the reverse-sweep MLP kernel (udf_mlp_rev.inc), used to decide
+"""CPU emulation of the split-precision arithmetic of the reverse-sweep MLP kernel (udf_mlp_rev32.inc), used to decide
 which MFMA passes the 1e-4 parity bar actually needs BEFORE any kernel is written.
 
 Every GEMM of the kernel is  z = Wh.xh + (Wh.xl + Wl.xh)/2^11  with f16 hi parts and f16 lo parts stored x2^11, fp32

@@ -380,7 +380,7 @@ def test_large_launches_are_bit_stable_run_to_run(prec, monkeypatch):
     """Determinism stress (DESIGN.md par. 3.1): repeated launches of the big kernels on the same inputs are bit-identical -
     the training backward (sweep + weight-gradient GEMMs + reduction) and the reverse-sweep value+gradient kernel in all four
     modes.  (Round 1's bf16x3 reverse kernel was neither stable nor right: all three split passes chained into ONE accumulator
-    set; with the cross terms in a second set - the f16x3 schedule - it is both, see udf_mlp_rev.inc.)"""
+    set; with the cross terms in a second set - the f16x3 schedule - it is both, see udf_mlp_rev32.inc.)"""
     net, state, cfg = mk("d8w256L10", prec)
     gen = torch.Generator().manual_seed(5)
     P = 131072

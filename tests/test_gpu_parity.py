@@ -124,7 +124,7 @@ def test_mlp_ragged_sizes_vs_oracle(P):
 
 @pytest.mark.parametrize("name,scale", [("d8w256L10", 1.0), ("d8w256L6", 1.0), ("d8w256L10_init", 1.7)])
 def test_reverse_mode_gradient(name, scale):
-    """Large grad launches (>= 10240 points in f16x3, >= 16384 in the single-pass modes) run the reverse-sweep kernel (udf_mlp_rev.inc), smaller ones the forward-mode
+    """Large grad launches (>= 10240 points in f16x3, >= 16384 in the single-pass modes) run the reverse-sweep kernel (udf_mlp_rev32.inc), smaller ones the forward-mode
     tangent kernel: both are UDFNetwork.gradient (udf_model.py:121-135) and must agree with the oracle and with each
     other; the reverse kernel (persistent workgroups, sigma' stashed through global memory) must be run-to-run
     deterministic, also with several tiles per workgroup (70001 points: ragged last tile, > 2 tiles per workgroup)."""
