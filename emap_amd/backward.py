@@ -155,7 +155,7 @@ class RenderFn(torch.autograd.Function):
 
     DIFF = ("edge", "depth", "gradient_error", "gradient_error_near_surface")
     # returned through the Function so that a loss which touches them fails loudly instead of silently dropping a term
-    GUARDED = ("udf", "weights", "normals", "gradients", "gradients_flip", "gradient_mag", "weight_sum")
+    GUARDED = ("udf", "weights", "normals", "gradients", "gradients_flip", "gradient_mag", "weight_sum", "alpha", "sparse_error")
 
     @staticmethod
     def forward(ctx, renderer, call, *params):
@@ -168,7 +168,12 @@ class RenderFn(torch.autograd.Function):
         N, S = call["N"], call["S"]
         outs = (v["edge"].view(N, 1), v["depth"].view(N, 1), v["scalars"][0], v["scalars"][1],
                 v["udf"].view(N, S), v["weights"].view(N, S), v["normals"].view(N, 3), v["gradients"].view(N, S, 3),
-                v["gradients_flip"].view(N, S, 3), v["gradient_mag"].view(N, S), v["weight_sum"].view(N, 1))
+                v["gradients_flip"].view(N, S, 3), v["gradient_mag"].view(N, S), v["weight_sum"].view(N, 1), v["alpha"].view(N, S),
+                v["scalars"][2])
+        # what the backward reads later must be what this forward used: the sample distance lives in a workspace the next render()
+        # of this shape overwrites (other near / far), the packed weights are re-packed after an optimizer step
+        v["_sd"] = v["_ws"][:4].clone()
+        ctx.packed_key = renderer.udf_network._pack_cache[_lib.PRECISIONS[call["prec_name"]]][0]
         return outs
 
     @staticmethod
@@ -179,6 +184,10 @@ class RenderFn(torch.autograd.Function):
                     f"emap_amd: the loss depends on render()['{k}'], whose gradient the HIP backward does not provide "
                     "(differentiable outputs: edge, depth, gradient_error, gradient_error_near_surface, variance, beta, gamma)")
         r, call, v = ctx.renderer, ctx.call, ctx.v
+        r.udf_network.packed(call["prec_name"])
+        if r.udf_network._pack_cache[_lib.PRECISIONS[call["prec_name"]]][0] != ctx.packed_key:
+            raise RuntimeError("emap_amd: the UDF network's parameters changed between render() and backward() (an optimizer step or an "
+                               "in-place edit in between): the gradient would be taken at other weights than the forward used")
         flat = r.backward_into(call, v, d_edge, d_depth, d_ge, d_ge_ns)
         lay = r._layout()
         need = [p.requires_grad for p in lay.tensors]

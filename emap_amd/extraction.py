@@ -43,6 +43,23 @@ def _fast_net(func, func_grad):
     return None
 
 
+def _uses_package_net(f) -> bool:
+    """True for a callable that evaluates this package's UDFNetwork point by point: the network's own bound methods, or a closure
+    over the network / over an object that owns one (the runner's normalising closure, runner_udf.py:520-527).  Such callables are
+    driven with 2^20-point launches; any OTHER callable keeps the caller's ``max_batch`` chunks (it may not act point by point, and
+    ``max_batch`` may be its memory bound)."""
+    from .udf_model import UDFNetwork
+    owns = lambda o: isinstance(o, UDFNetwork) or isinstance(getattr(o, "udf_network", None), UDFNetwork)
+    if owns(getattr(f, "__self__", None)):
+        return True
+    cells = [c.cell_contents for c in (getattr(f, "__closure__", None) or []) if c is not None]
+    return any(owns(o) for o in cells) or any(owns(o) for o in (getattr(f, "__defaults__", None) or ()))
+
+
+def _chunk(func, func_grad, max_batch, mult=1):
+    return _BIG if (_uses_package_net(func) and _uses_package_net(func_grad)) else max(int(max_batch) * mult, 1)
+
+
 def _eval(fn, pts, chunk):
     return torch.cat([fn(pts[h:h + chunk]) for h in range(0, pts.shape[0], chunk)]) if pts.shape[0] else fn(pts)
 
@@ -71,7 +88,7 @@ def get_udf_normals_grid(func, func_grad, N, udf_threshold, is_linedirection=Fal
         if net is not None:
             df = _eval(lambda p: net.hip_udf(p, with_grad=False)[0], pts, _BIG)
         else:
-            df = _eval(lambda p: func(p)[0].detach(), pts, _BIG)
+            df = _eval(lambda p: func(p)[0].detach(), pts, _chunk(func, func_grad, max_batch))
         samples[:, 3:4] = df
 
         norm_idx = torch.where(samples[:, 3] < udf_threshold)[0]            # :64-65
@@ -79,7 +96,7 @@ def get_udf_normals_grid(func, func_grad, N, udf_threshold, is_linedirection=Fal
         if net is not None:
             grad = _eval(lambda p: net.hip_udf(p, with_grad=True)[1], sub, _BIG).reshape(-1, 1, 3) if len(norm_idx) else sub.reshape(-1, 1, 3)
         else:
-            grad = _eval(lambda p: func_grad(p).detach(), sub, _BIG) if len(norm_idx) else sub.reshape(-1, 1, 3)
+            grad = _eval(lambda p: func_grad(p).detach(), sub, _chunk(func, func_grad, max_batch)) if len(norm_idx) else sub.reshape(-1, 1, 3)
         # the reference normalises the (P,1,3) gradient along dim=1 - the singleton - i.e. per component (:71)
         samples[norm_idx, 4:7] = -torch.nn.functional.normalize(grad, dim=1)[:, 0]
 
@@ -92,7 +109,7 @@ def get_udf_normals_grid(func, func_grad, N, udf_threshold, is_linedirection=Fal
             if net is not None:
                 grad_ld = _eval(lambda p: net.hip_udf(p, with_grad=True)[1], ld_pts, _BIG)
             else:
-                grad_ld = _eval(lambda p: func_grad(p).detach().reshape(-1, 3), ld_pts, _BIG)
+                grad_ld = _eval(lambda p: func_grad(p).detach().reshape(-1, 3), ld_pts, _chunk(func, func_grad, max_batch, sampling_N))
             samples[norm_idx, 8:11] = null_direction(grad_ld.reshape(len(norm_idx), sampling_N, 3))
 
     df_values = samples[:, 3].reshape(N, N, N)
@@ -120,8 +137,8 @@ def get_udf_normals_slow(func, func_grad, voxel_size, xyz, is_linedirection, sam
             df = torch.cat([r[0] for r in res]) if n else pts[:, :1]
             grad = torch.cat([r[1] for r in res]) if n else pts
         else:
-            df = _eval(lambda p: func(p)[0].detach(), pts, _BIG)
-            grad = _eval(lambda p: func_grad(p).detach()[:, 0], pts, _BIG)
+            df = _eval(lambda p: func(p)[0].detach(), pts, _chunk(func, func_grad, max_batch))
+            grad = _eval(lambda p: func_grad(p).detach()[:, 0], pts, _chunk(func, func_grad, max_batch))
         samples[:, 3] = df.squeeze(-1)
         samples[:, 4:7] = -torch.nn.functional.normalize(grad, dim=1)                     # :158-160
         if is_linedirection and n:
@@ -132,6 +149,6 @@ def get_udf_normals_slow(func, func_grad, voxel_size, xyz, is_linedirection, sam
             if net is not None:
                 grad_ld = _eval(lambda p: net.hip_udf(p, with_grad=True)[1], ld_pts, _BIG)
             else:
-                grad_ld = _eval(lambda p: func_grad(p.float()).detach()[:, 0], ld_pts, _BIG)
+                grad_ld = _eval(lambda p: func_grad(p.float()).detach()[:, 0], ld_pts, _chunk(func, func_grad, max_batch, sampling_N))
             samples[:, 7:10] = null_direction(grad_ld.reshape(n, sampling_N, 3))
     return samples[:, 3], samples[:, 4:7], samples[:, 7:10], samples

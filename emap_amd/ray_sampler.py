@@ -88,8 +88,14 @@ class DeviceRaySampler:
                             pix.data_ptr(), img.data_ptr())
         pin = None
         if pixels is not None:
-            pin = pixels.to(dev).to(torch.int64).contiguous()
-            assert pin.shape == (N, 2)
+            px = torch.as_tensor(pixels)
+            assert px.shape == (N, 2)
+            if px.device.type == "cpu":      # given pixels index the edge maps in the kernel: reject out-of-range ones where it is free
+                if bool(((px[:, 0] < 0) | (px[:, 0] >= self.W) | (px[:, 1] < 0) | (px[:, 1] >= self.H)).any()):
+                    raise ValueError(f"DeviceRaySampler: pixels outside the {self.W}x{self.H} image")
+                pin = px.to(torch.int64).to(dev).contiguous()
+            else:                            # device pixels: clamped on the device (no host synchronisation)
+                pin = torch.stack([px[:, 0].clamp(0, self.W - 1), px[:, 1].clamp(0, self.H - 1)], -1).to(torch.int64).contiguous()
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().emap_sample_rays(C.byref(self._ds), -1 if img_idx is None else int(img_idx), N, int(bool(importance_sample)),
                                                    self.seed, 0, _lib.ptr(self._counter), _lib.ptr(pin), C.byref(out),

@@ -244,7 +244,7 @@ class UDFRendererBlending:
             ws = _workspace(self._bws, (N, S, prec), nb.value, dev)
             _lib.check(L.emap_render_bwd_staged(C.byref(cfg), _lib.ptr(net.packed(call["prec_name"])), prec, C.byref(p),
                                                 _lib.ptr(call["ro"]), _lib.ptr(call["rd"]), _lib.ptr(call["ds"]), _lib.ptr(v["z_vals"]),
-                                                _lib.ptr(v["udf"]), _lib.ptr(v["gradients"]), _lib.ptr(v["_ws"]), C.byref(cg), C.byref(pg),
+                                                _lib.ptr(v["udf"]), _lib.ptr(v["gradients"]), _lib.ptr(v.get("_sd", v["_ws"])), C.byref(cg), C.byref(pg),
                                                 _lib.ptr(ws), ws.numel(), _lib.ptr(self._err), _lib.stream_ptr(dev), int(stages)),
                        "render_bwd")
         return flat
@@ -317,7 +317,8 @@ class UDFRendererBlending:
             "inside_sphere": v["inside_sphere"].view(N, S), "gradient_mag": out["gradient_mag"],
             "mid_z_vals": v["mid_z"].view(N, S), "dists": v["dists"].view(N, S),
             # extras (not in the reference dict)
-            "z_vals": v["z_vals"].view(N, S), "alpha": v["alpha"].view(N, S), "sparse_error": v["scalars"][2],
+            "z_vals": v["z_vals"].view(N, S), "alpha": out.get("alpha", v["alpha"].view(N, S)),
+            "sparse_error": out.get("sparse_error", v["scalars"][2]),
             "eikonal_sums": v["scalars"][3:7],
         }
 

@@ -267,3 +267,25 @@ def test_dropin_reroutes_the_dataset_method_and_the_validation_loop(monkeypatch)
     assert dropin.patch_runner() and not dropin.patch_runner()                  # wrapped once
     r = Runner_UDF()
     assert r.validate(idx=3) == 3 and seen == {"reduced": True, "grad": False} and r.renderer.inference_reduced is False
+
+
+def test_extraction_chunking_policy():
+    """Advisor r2: only callables that evaluate THIS package's network (its bound methods, the runner's closure over it) are driven with
+    2^20-point launches; any other callable keeps the caller's max_batch (x sampling_N for the line-direction pass)."""
+    import emap_amd
+    from emap_amd import extraction as E
+    net = emap_amd.UDFNetwork(d_in=3, d_out=1, d_hidden=128, n_layers=4, skip_in=(4,), multires=6)
+
+    def closure(x):                      # runner_udf.py:522-526 shape: closes over the network
+        return net.gradient(x)
+
+    class Runner:
+        udf_network = net
+
+    r = Runner()
+    via_owner = lambda x: r.udf_network.gradient(x)
+    foreign = lambda x: x * 2
+    assert E._uses_package_net(net.udf) and E._uses_package_net(closure) and E._uses_package_net(via_owner)
+    assert not E._uses_package_net(foreign) and not E._uses_package_net(len)
+    assert E._chunk(net.udf, closure, 4096) == E._BIG == 1 << 20
+    assert E._chunk(net.udf, foreign, 4096) == 4096 and E._chunk(foreign, foreign, 128, 50) == 6400
