@@ -434,6 +434,14 @@ def main():
     kms, kn = C.c_float(), C.c_int()
     _lib.check(L.emap_profile_read_kernel(which, C.byref(kms), C.byref(kn)))
     k_avg_s = (kms.value / max(kn.value, 1)) * 1e-3
+    kclk = C.c_float()   # shader clock during the last profiled launch of the dominant kernel (s_memtime / s_memrealtime inside the kernel)
+    _lib.check(L.emap_profile_read_clock(which, C.byref(kclk)))
+    bwd_us = None
+    if a.mode == "train":   # per-step sums of the two big backward kernels (all chunks of a step)
+        wms, wn = C.c_float(), C.c_int()
+        _lib.check(L.emap_profile_read_kernel(2, C.byref(wms), C.byref(wn)))
+        bwd_us = {"udf_mlp_vjp_us_per_step": kms.value * 1e3 / n_prof, "wgrad_us_per_step": wms.value * 1e3 / n_prof,
+                  "launches_per_step": [max(kn.value, 1) / n_prof, max(wn.value, 1) / n_prof]}
     launches_per_step = max(kn.value, 1) / n_prof      # > 1 when the backward sweep runs in chunks of 65 536 points (> 512 rays per GPU)
     loss_now = trainer.last_stats.tolist() if trainer is not None else None
 
@@ -480,12 +488,18 @@ def main():
                          "frac": ach / MFMA_PEAK_TFLOPS, "avg_launch_us": k_avg_s * 1e6, "launches": kn.value,
                          "algorithmic_flops_per_launch": flops_launch, "traffic": None,
                          # the sustained dense f16 rate measured on this hardware (profiles/r02_probe_mfma_sustained.txt), SURVEY par. 8d
-                         "peak_measured": MFMA_MEASURED_TFLOPS, "frac_of_measured_peak": ach / MFMA_MEASURED_TFLOPS},
+                         "peak_measured": MFMA_MEASURED_TFLOPS, "frac_of_measured_peak": ach / MFMA_MEASURED_TFLOPS,
+                         # the kernel runs at the 1400 W package power cap on real data (profiles/r03_probe_power.txt): the shader clock it
+                         # actually got, and the nominal peak scaled to it (2.5 PF/s is quoted at 2.4 GHz)
+                         "shader_clock_mhz": (kclk.value or None),
+                         "frac_of_peak_at_measured_clock": (ach / (MFMA_PEAK_TFLOPS * kclk.value / 2400.0) if kclk.value else None)},
             "whole_step_algorithmic_tflops": value * alg / 1e12,
             "whole_step_frac_of_mfma_peak": value * alg / 1e12 / MFMA_PEAK_TFLOPS / world,
         }
         if loss_now is not None:
             line["loss_after_run"] = loss_now
+        if bwd_us is not None:
+            line["backward_kernels"] = bwd_us
         if parity is not None:
             line["parity"] = parity
         tpath = os.path.join(ROOT, "profiles", "r03_traffic.json")

@@ -21,7 +21,7 @@ PREC_F16X3 = 3
 PRECISIONS = {"bf16": PREC_BF16, "bf16x3": PREC_BF16X3, "f16": PREC_F16, "f16x3": PREC_F16X3}
 UDF_TYPES = {"abs": 0, "square": 1, "sdf": 2}
 MAX_LIN = 12
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 F_NAN_SAMPLES = 1
 F_NAN_GRADERR = 2
@@ -112,6 +112,7 @@ SYMBOLS = {
     "emap_profile_enable": (C.c_int, [C.c_int]),
     "emap_profile_read": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "emap_profile_read_kernel": (C.c_int, [C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    "emap_profile_read_clock": (C.c_int, [C.c_int, C.POINTER(C.c_float)]),
     "emap_linspace_host": (None, [C.c_float, C.c_float, C.c_int, C.POINTER(C.c_float)]),
 }
 

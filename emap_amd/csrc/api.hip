@@ -37,6 +37,7 @@ static bool g_prof_on = false;
 static int g_prof_n[PROF_KERNELS] = {0, 0, 0};
 static hipEvent_t g_prof_ev[PROF_KERNELS][PROF_MAX][2];
 static bool g_prof_init = false;
+static long long* g_clk_dev = nullptr;
 struct ProfScope {   // records a HIP event pair around one launch on its stream while profiling is enabled
     int k; hipStream_t st; bool on;
     ProfScope(int k_, hipStream_t st_) : k(k_), st(st_), on(g_prof_on && g_prof_n[k_] < PROF_MAX) { if (on) (void)hipEventRecord(g_prof_ev[k][g_prof_n[k]][0], st); }
@@ -553,6 +554,25 @@ int emap_profile_enable(int on) {
     }
     g_prof_on = on != 0;
     if (on) for (int k = 0; k < PROF_KERNELS; ++k) g_prof_n[k] = 0;
+    // shader-clock stamps of the two big MLP kernels (udf_mlp_kernel.inc:clock_stamp): a device buffer on the current device while
+    // profiling is on; the launchers pass null otherwise
+    if (on && !g_clk_dev) {
+        if (hipMalloc(reinterpret_cast<void**>(&g_clk_dev), 8 * sizeof(long long)) != hipSuccess) { g_clk_dev = nullptr; set_error("hipMalloc failed"); return EMAP_E_LAUNCH; }
+    }
+    if (on && hipMemset(g_clk_dev, 0, 8 * sizeof(long long)) != hipSuccess) { set_error("hipMemset failed"); return EMAP_E_LAUNCH; }
+    emap::g_prof_clk = on ? g_clk_dev : nullptr;
+    return EMAP_OK;
+}
+
+int emap_profile_read_clock(int which, float* mhz_host) {
+    if (!mhz_host || (which != 0 && which != 1)) { set_error("profile_read_clock: bad argument"); return EMAP_E_INVALID; }
+    *mhz_host = 0.f;
+    if (!g_clk_dev) return EMAP_OK;
+    long long h[8];
+    if (hipMemcpy(h, g_clk_dev, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) { set_error("hipMemcpy failed"); return EMAP_E_LAUNCH; }
+    const long long* s = h + 4 * which;        // {memtime, realtime} at entry, {memtime, realtime} at exit, of the LAST launch
+    const long long dt = s[2] - s[0], dr = s[3] - s[1];
+    if (dt > 0 && dr > 0) *mhz_host = (float)((double)dt / (double)dr * 100.0);
     return EMAP_OK;
 }
 

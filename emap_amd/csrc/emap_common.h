@@ -125,7 +125,10 @@ int launch_null_direction(const float* g, int64_t n, int k, float* dir, hipStrea
 // (K = columns: 64 per tile = 2 K-steps).  A "level" is a set of feature rows: rt row tiles x 2 K-steps x 1 KiB.
 //   A level 0 = PE slots (4 row tiles), A level l+1 = output of hidden layer l; Z level l = adjoint of layer l's pre-activation
 constexpr int VJP_PT = 32;
-constexpr int VJP_CHUNK_TILES = 2048;   // tiles per sweep launch (bounds the stash: 2048 x ~0.5 MiB)
+#ifndef EMAP_VJP_CHUNK_TILES
+#define EMAP_VJP_CHUNK_TILES 2048
+#endif
+constexpr int VJP_CHUNK_TILES = EMAP_VJP_CHUNK_TILES;   // tiles per sweep launch (bounds the stash: 2048 x ~0.5 MiB)
 constexpr int WGRAD_MAX_JOBS = 2 * EMAP_MAX_LIN;
 struct VjpLayout {
     int32_t a_rt[EMAP_MAX_LIN + 1], a_off[EMAP_MAX_LIN + 1];   // row tiles / KiB offset inside a tile's A block
@@ -146,6 +149,7 @@ struct WgradJob {
 
 
 bool mlp_uses_rev(const NetLayout& L, int prec, int64_t P);
+extern long long* g_prof_clk;   // device buffer of 8 x int64 while emap_profile_enable(1) is in effect, else null (clock_stamp in udf_mlp_kernel.inc)
 constexpr int REV_MAX_WG = 768;      // persistent workgroups of the reverse-mode kernel (3 per CU)
 inline size_t rev_scratch_bytes(const NetLayout& L) {   // sigmoid stash: [workgroup][layer][pair][4][64 lanes x 16 B]
     return L.has_rev ? (size_t)(REV_MAX_WG * 2 / 3) * (size_t)(L.n_lin - 1) * (size_t)(L.H / 32) * 4096 : 0;   // 2 resident workgroups per CU

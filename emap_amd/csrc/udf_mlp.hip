@@ -6,6 +6,8 @@
 #include <string.h>
 
 namespace emap {
+long long* g_prof_clk = nullptr;
+
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EMAP_ABI_VERSION 4
+#define EMAP_ABI_VERSION 5
 
 /* error codes */
 #define EMAP_OK 0
@@ -325,6 +325,10 @@ int emap_profile_read(float* total_ms_host, int* launches_host);
 /* which: 0 = final value+gradient MLP pass of emap_render_fwd (same as emap_profile_read), 1 = udf_mlp_vjp sweep,
  * 2 = weight-gradient GEMMs (both inside emap_render_bwd / emap_udf_vjp) */
 int emap_profile_read_kernel(int which, float* total_ms_host, int* launches_host);
+/* Shader clock (MHz) during the LAST launch, while profiling was enabled, of which = 0: the reverse-sweep value+gradient kernel,
+ * 1: the udf_mlp_vjp sweep - s_memtime (shader cycles) over s_memrealtime (100 MHz) between the entry and the exit of workgroup 0.
+ * 0 if no such launch was recorded.  (The dominant kernel runs at the package power cap on real data: DESIGN.md par. 5.) */
+int emap_profile_read_clock(int which, float* mhz_host);
 
 /* host-only: torch.linspace(start, end, steps) in fp32, the grid of sample_pdf's u / the coarse z_vals */
 void emap_linspace_host(float start, float end, int steps, float* out_host);
