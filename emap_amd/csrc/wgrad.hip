@@ -182,9 +182,12 @@ __device__ __forceinline__ void wgrad_lds_run(const WgradArgs& a, const WgradJob
             V8 z[2];
             z[0] = *reinterpret_cast<const V8*>(st + (CT + zr[0]) * 1024);
             z[1] = *reinterpret_cast<const V8*>(st + (CT + zr[1]) * 1024);
+            if ((u & 1) == 0) {           // the value columns of a tile are exactly its K-step 0 (udf_mlp_vjp.inc: K slot <-> column map)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)   // value columns are K slots e with e % 4 < 2
-                bsum[i] += ((float)z[i][0] + (float)z[i][1]) + ((float)z[i][4] + (float)z[i][5]);
+                for (int i = 0; i < 2; ++i)
+                    bsum[i] += (((float)z[i][0] + (float)z[i][1]) + ((float)z[i][2] + (float)z[i][3])) +
+                               (((float)z[i][4] + (float)z[i][5]) + ((float)z[i][6] + (float)z[i][7]));
+            }
 #pragma unroll
             for (int c = 0; c < CT; ++c) {
                 const V8 af = *reinterpret_cast<const V8*>(st + c * 1024);
