@@ -101,7 +101,7 @@ static VjpPlan plan_vjp(const NetLayout& L, int64_t P) {
     VjpPlan pl;
     build_vjp_layout(L, &pl.V);
     const int cus = device_cus();
-    pl.sweep_grid = (L.H == 256) ? cus : 2 * cus;          // 8 waves: one workgroup per CU; 4 waves: two
+    pl.sweep_grid = (L.H == 256 && VJP_NW_256 == 8) ? cus : 2 * cus;          // 8 waves: one workgroup per CU; 4 waves: two
     const int64_t tiles = (P + VJP_PT - 1) / VJP_PT;
     pl.chunk_tiles = (int)std::min<int64_t>(std::max<int64_t>(tiles, 1), VJP_CHUNK_TILES);
     const size_t pfl = plan_wgrad(L, pl.V, cus, pl.jobs, &pl.n_jobs, pl.job_h, pl.job_pe, &pl.wgrad_wg);

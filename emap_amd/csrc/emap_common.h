@@ -129,6 +129,10 @@ constexpr int VJP_PT = 32;
 #define EMAP_VJP_CHUNK_TILES 2048
 #endif
 constexpr int VJP_CHUNK_TILES = EMAP_VJP_CHUNK_TILES;   // tiles per sweep launch (bounds the stash: 2048 x ~0.5 MiB)
+#ifndef EMAP_VJP_NW256
+#define EMAP_VJP_NW256 8
+#endif
+constexpr int VJP_NW_256 = EMAP_VJP_NW256;   // waves per workgroup of the sweep at d_hidden = 256: 8 (one workgroup per CU; measured 876-880 us) or 4 (two tile pairs per wave, two workgroups per CU: 939-958 us, 22 % more cycles)
 constexpr int WGRAD_MAX_JOBS = 2 * EMAP_MAX_LIN;
 struct VjpLayout {
     int32_t a_rt[EMAP_MAX_LIN + 1], a_off[EMAP_MAX_LIN + 1];   // row tiles / KiB offset inside a tile's A block
