@@ -127,7 +127,10 @@ __device__ __forceinline__ void wgrad_store(const WgradArgs& a, const WgradJob& 
 // steps in flight (no registers are involved, so nothing the compiler could copy: loads stay in flight across the loop
 // back-edge); per step: s_waitcnt vmcnt (my fragments of this step have landed) -> s_barrier (everyone's have, and everyone
 // has finished reading the stage about to be refilled) -> issue step u + D -> 18 ds_read_b128 + 32 MFMAs.
-constexpr int WGRAD_DEPTH = 3;   // steps (32 KiB each) in flight per workgroup; the ring has WGRAD_DEPTH + 1 stages (<= 160 KiB of LDS)
+#ifndef EMAP_WGRAD_DEPTH
+#define EMAP_WGRAD_DEPTH 3
+#endif
+constexpr int WGRAD_DEPTH = EMAP_WGRAD_DEPTH;   // steps (32 KiB each) in flight per workgroup; the ring has WGRAD_DEPTH + 1 stages (<= 160 KiB of LDS)
 __device__ __forceinline__ void wg_dma16(unsigned lds_dst, const char* gsrc) {
     unsigned keep;   // M0 = LDS byte address of lane 0's 16 bytes; written in the statement that uses it (the compiler owns M0)
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
@@ -182,11 +185,12 @@ __device__ __forceinline__ void wgrad_lds_run(const WgradArgs& a, const WgradJob
             V8 z[2];
             z[0] = *reinterpret_cast<const V8*>(st + (CT + zr[0]) * 1024);
             z[1] = *reinterpret_cast<const V8*>(st + (CT + zr[1]) * 1024);
-            if ((u & 1) == 0) {           // the value columns of a tile are exactly its K-step 0 (udf_mlp_vjp.inc: K slot <-> column map)
+            {   // the value columns of a tile are exactly its K-step 0 (udf_mlp_vjp.inc: K slot <-> column map)
+                const float m = (u & 1) ? 0.0f : 1.0f;
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
-                    bsum[i] += (((float)z[i][0] + (float)z[i][1]) + ((float)z[i][2] + (float)z[i][3])) +
-                               (((float)z[i][4] + (float)z[i][5]) + ((float)z[i][6] + (float)z[i][7]));
+                    bsum[i] = fmaf(m, (((float)z[i][0] + (float)z[i][1]) + ((float)z[i][2] + (float)z[i][3])) +
+                                      (((float)z[i][4] + (float)z[i][5]) + ((float)z[i][6] + (float)z[i][7])), bsum[i]);
             }
 #pragma unroll
             for (int c = 0; c < CT; ++c) {
@@ -200,9 +204,15 @@ __device__ __forceinline__ void wgrad_lds_run(const WgradArgs& a, const WgradJob
     wgrad_store<CT>(a, J, slice, wave, lane, acc, bsum);
 }
 
+#ifdef EMAP_WGRAD_TIMING
+static __device__ long long emap_wg_times[1024 * 2];   // debug builds: per workgroup {job, s_memrealtime ticks (100 MHz)}
+#endif
 template <class V8>
 __global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) char wg_smem[];
+#ifdef EMAP_WGRAD_TIMING
+    const long long wg_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     int ji = 0;
     while (ji + 1 < a.n_jobs && (int)blockIdx.x >= a.job[ji + 1].first_wg) ++ji;
     const WgradJob J = a.job[ji];
@@ -214,6 +224,9 @@ __global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgradArgs a) {
     else if (nb == 2) wgrad_lds_run<V8, 2>(a, J, slice, wave, lane, wg_smem);
     else if (nb == 3) wgrad_lds_run<V8, 3>(a, J, slice, wave, lane, wg_smem);
     else wgrad_lds_run<V8, 4>(a, J, slice, wave, lane, wg_smem);
+#ifdef EMAP_WGRAD_TIMING
+    if (threadIdx.x == 0 && blockIdx.x < 1024) { emap_wg_times[2 * blockIdx.x] = ji; emap_wg_times[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - wg_t0; }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -417,17 +430,35 @@ size_t plan_wgrad(const NetLayout& L, const VjpLayout& V, int wg_budget, WgradJo
             J.a_off = (part == 0) ? V.a_off[l] : V.a_off[0];
             J.a_ct = (part == 0) ? (d.in_prev + 15) / 16 : 2 * PE_KS;
             J.bias_off = -1;
-            cost[n] = (double)((J.z_rt + 7) / 8) * (1.0 + J.a_ct);   // per tile: Z fragment loads + A fragments streamed per wave
+            // a slice is bound by what it streams per K-step (round 3: with the cost counted in MFMAs the two PE jobs - 20 KiB per step for
+            // a quarter of the MFMAs - got a third of the slices their bytes needed and ran 2.2x longer than everyone else: 334 us,
+            // 3.6 TB/s; per-workgroup stamps then showed the one-row last layer paying for its 16 clamped Z fetches like a full level)
+            // 1 KiB fetches per K-step and workgroup: A fragments + Z fetches; the clamped duplicates of a short Z level hit in L2 and
+            // count about half (measured: the one-row last layer ran 294 us with 15 slices, 188 us with 28, next to 240 us)
+            cost[n] = (double)J.a_ct + (double)J.z_rt + 0.5 * (double)(16 - (J.z_rt < 16 ? J.z_rt : 16));
             tot += cost[n];
             (part == 0 ? job_h : job_pe)[l] = n;
             ++n;
         }
     }
+    // slices ~ cost, the whole budget handed out (largest remainders first)
+    int sl[WGRAD_MAX_JOBS], given = 0;
+    double rem[WGRAD_MAX_JOBS];
+    for (int i = 0; i < n; ++i) {
+        const double x = cost[i] / tot * wg_budget;
+        sl[i] = (int)x < 1 ? 1 : (int)x;
+        rem[i] = x - (double)sl[i];
+        given += sl[i];
+    }
+    while (given < wg_budget) {
+        int b = 0;
+        for (int i = 1; i < n; ++i) if (rem[i] > rem[b]) b = i;
+        ++sl[b]; rem[b] -= 1.0; ++given;
+    }
     int wg = 0;
     size_t floats = 0;
     for (int i = 0; i < n; ++i) {
-        int s = (int)(cost[i] / tot * wg_budget);
-        if (s < 1) s = 1;
+        const int s = sl[i];
         jobs[i].n_slices = s;
         jobs[i].first_wg = wg;
         wg += s;
@@ -495,3 +526,8 @@ int launch_wgrad_reduce(const NetLayout& L, const WgradJob* jobs, int n_jobs, co
 }
 
 }  // namespace emap
+#ifdef EMAP_WGRAD_TIMING
+extern "C" int emap_debug_wgrad_times(long long* dst, int n) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(emap::emap_wg_times), (size_t)n * sizeof(long long));
+}
+#endif
