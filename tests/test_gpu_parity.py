@@ -876,26 +876,30 @@ def test_captured_graph_survives_renders_of_other_shapes():
 
 
 def test_profile_hooks_report_kernel_time_and_shader_clock():
-    """emap_profile_enable / read_kernel / read_clock (include/emap_hip.h): HIP events around the value+gradient pass on its stream and the
-    shader clock the kernel's workgroup 0 saw (s_memtime over s_memrealtime); results are unaffected by the hooks."""
+    """emap_profile_enable / read_kernel / read_clock (include/emap_hip.h): HIP events around the final value+gradient pass of emap_render_fwd on
+    its stream, and the shader clock that kernel's workgroup 0 saw (s_memtime over s_memrealtime); results are unaffected by the hooks."""
     net, state, cfg = mk("d8w256L10")
+    r = mk_renderer(net, 64, 64, 4)
     L = _lib.lib()
-    x = (torch.rand(65536, 3, device=DEV) * 2 - 1)
-    with torch.no_grad():
-        u0, g0 = net.hip_udf(x, with_grad=True)
-        _lib.check(L.emap_profile_enable(1))
-        try:
-            for _ in range(3):
-                u1, g1 = net.hip_udf(x, with_grad=True)
-            torch.cuda.synchronize()
-        finally:
-            _lib.check(L.emap_profile_enable(0))
+    ro, rd, near, far, ds = (v.to(DEV) for v in synthetic.make_rays(512, seed=1))
+    tr = torch.zeros(512, 1, device=DEV)
+
+    def render():
+        with torch.no_grad():
+            return r.render(ro, rd, near, far, ds, cos_anneal_ratio=1.0, flip_saturation=0.9, t_rand=tr)
+    out0 = render()
+    _lib.check(L.emap_profile_enable(1))
+    try:
+        for _ in range(3):
+            out1 = render()
+        torch.cuda.synchronize()
+    finally:
+        _lib.check(L.emap_profile_enable(0))
     ms, n, mhz = C.c_float(), C.c_int(), C.c_float()
     _lib.check(L.emap_profile_read_kernel(0, C.byref(ms), C.byref(n)))
     _lib.check(L.emap_profile_read_clock(0, C.byref(mhz)))
     assert n.value == 3 and 0.05 < ms.value / 3 < 5.0            # a few hundred microseconds per launch
     assert 500.0 < mhz.value < 2600.0                            # power-capped well below the 2.4 GHz nominal clock on real data
-    assert torch.equal(u0, u1) and torch.equal(g0, g1)
-    with torch.no_grad():                                        # hooks off: the kernel gets no clock buffer
-        u2, g2 = net.hip_udf(x, with_grad=True)
-    assert torch.equal(u0, u2) and torch.equal(g0, g2)
+    out2 = render()                                              # hooks off again: the kernel gets no clock buffer
+    for k in ("edge", "depth", "udf", "gradients"):
+        assert torch.equal(out0[k], out1[k]) and torch.equal(out0[k], out2[k])
