@@ -139,9 +139,10 @@ class UdfFn(torch.autograd.Function):
         nb = C.c_size_t()
         with _lib.on_device(xs):
             _lib.check(L.emap_udf_vjp_workspace_bytes(C.byref(cfg), prec, P, C.byref(nb)), "udf_vjp_workspace_bytes")
-            ws = _workspace(net._vjp_ws, ("udf", P), nb.value, dev)
+            nbytes = nb.value if net.backward_workspace_limit is None else min(nb.value, int(net.backward_workspace_limit))
+            ws = _workspace(net._vjp_ws, ("udf", P), nbytes, dev)
             _lib.check(L.emap_udf_vjp(C.byref(cfg), _lib.ptr(net.packed()), prec, _lib.ptr(xs), P, _lib.ptr(du), _lib.ptr(dg),
-                                      C.byref(pg), _lib.ptr(ws), ws.numel(), _lib.ptr(net.err_word(dev)), _lib.stream_ptr(dev)),
+                                      C.byref(pg), _lib.ptr(ws), min(ws.numel(), nbytes), _lib.ptr(net.err_word(dev)), _lib.stream_ptr(dev)),
                        "udf_vjp")
         need = [p.requires_grad for p in lay.tensors]
         dx = None

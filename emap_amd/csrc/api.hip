@@ -97,7 +97,10 @@ struct VjpPlan {
     size_t off_absmax, off_slab, off_partial, off_ldot, off_a, off_z, total;
 };
 
-static VjpPlan plan_vjp(const NetLayout& L, int64_t P) {
+// avail = 0: the preferred plan (chunks of up to VJP_CHUNK_TILES tiles); avail > 0: the largest chunk whose stash fits into a workspace of
+// `avail` bytes - the caller bounds the memory, the backward runs in more chunks (chunk_tiles = 0: not even VJP_MIN_CHUNK_TILES fit)
+constexpr int VJP_MIN_CHUNK_TILES = 256;
+static VjpPlan plan_vjp(const NetLayout& L, int64_t P, size_t avail = 0) {
     VjpPlan pl;
     build_vjp_layout(L, &pl.V);
     const int cus = device_cus();
@@ -110,10 +113,23 @@ static VjpPlan plan_vjp(const NetLayout& L, int64_t P) {
     pl.off_slab = off; off += (size_t)pl.sweep_grid * pl.V.s_slab_kb * 1024;
     pl.off_partial = off; off += ((pfl * 4 + 255) & ~(size_t)255);
     pl.off_ldot = off; off += (((size_t)std::max<int64_t>(tiles, 1) * 4 + 255) & ~(size_t)255);
+    const size_t per_tile = ((size_t)pl.V.a_tile_kb + (size_t)pl.V.z_tile_kb) * 1024;
+    if (avail > 0) {
+        const size_t fit = avail > off ? (avail - off) / per_tile : 0;
+        const int64_t need = std::min<int64_t>(std::max<int64_t>(tiles, 1), VJP_MIN_CHUNK_TILES);
+        pl.chunk_tiles = (int64_t)fit < need ? 0 : (int)std::min<size_t>(fit, (size_t)pl.chunk_tiles);
+    }
     pl.off_a = off; off += (size_t)pl.chunk_tiles * pl.V.a_tile_kb * 1024;
     pl.off_z = off; off += (size_t)pl.chunk_tiles * pl.V.z_tile_kb * 1024;
     pl.total = off;
     return pl;
+}
+// bytes of the smallest workspace plan_vjp accepts for P points
+static size_t vjp_min_bytes(const NetLayout& L, int64_t P) {
+    const VjpPlan pl = plan_vjp(L, P);
+    const int64_t tiles = (P + VJP_PT - 1) / VJP_PT;
+    const size_t per_tile = ((size_t)pl.V.a_tile_kb + (size_t)pl.V.z_tile_kb) * 1024;
+    return pl.off_a + (size_t)std::min<int64_t>(std::max<int64_t>(tiles, 1), VJP_MIN_CHUNK_TILES) * per_tile;
 }
 
 // d/dtheta of sum_p du[p] udf(x_p) + dg[p] . grad udf(x_p); absmax must already hold max|du|, max|dg| of the launch
@@ -424,8 +440,8 @@ int emap_udf_vjp(const EmapNetConfig* cfg, const void* packed, int prec, const f
     if (P < 0 || !packed || !workspace || (P > 0 && (!x || !d_udf || !d_grad3))) { set_error("udf_vjp: null pointer"); return EMAP_E_INVALID; }
     rc = check_param_grads(L, out, "udf_vjp");
     if (rc) return rc;
-    const VjpPlan pl = plan_vjp(L, P);
-    if (workspace_bytes < pl.total) { set_error("udf_vjp: workspace %zu < %zu bytes", workspace_bytes, pl.total); return EMAP_E_WORKSPACE; }
+    const VjpPlan pl = plan_vjp(L, P, workspace_bytes ? workspace_bytes : 1);
+    if (pl.chunk_tiles <= 0) { set_error("udf_vjp: workspace %zu < %zu bytes (minimum; emap_udf_vjp_workspace_bytes is the preferred size)", workspace_bytes, vjp_min_bytes(L, P)); return EMAP_E_WORKSPACE; }
     char* ws = static_cast<char*>(workspace);
     hipStream_t st = static_cast<hipStream_t>(stream);
     rc = launch_absmax(d_udf, d_grad3, P, reinterpret_cast<uint32_t*>(ws + pl.off_absmax), st);
@@ -500,8 +516,8 @@ int emap_render_bwd_staged(const EmapNetConfig* cfg, const void* packed, int pre
     const int S = p->n_samples + m * (m > 0 ? p->up_sample_steps : 0);
     size_t o_du, o_dg, o_part;
     const size_t extra = render_bwd_extra(*p, &o_du, &o_dg, &o_part);
-    const VjpPlan pl = plan_vjp(L, (int64_t)N * S);
-    if (workspace_bytes < extra + pl.total) { set_error("render_bwd: workspace %zu < %zu bytes", workspace_bytes, extra + pl.total); return EMAP_E_WORKSPACE; }
+    const VjpPlan pl = plan_vjp(L, (int64_t)N * S, workspace_bytes > extra ? workspace_bytes - extra : 1);
+    if (pl.chunk_tiles <= 0) { set_error("render_bwd: workspace %zu < %zu bytes (minimum; emap_render_bwd_workspace_bytes is the preferred size)", workspace_bytes, extra + vjp_min_bytes(L, (int64_t)N * S)); return EMAP_E_WORKSPACE; }
     char* ws = static_cast<char*>(workspace);
     char* vws = ws + extra;
     hipStream_t st = static_cast<hipStream_t>(stream);

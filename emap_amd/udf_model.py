@@ -78,6 +78,9 @@ class UDFNetwork(nn.Module):
         self.relu = nn.ReLU()
         self._pack_cache = {}
         self._vjp_ws = {}
+        # upper bound in bytes on the backward's workspace (None: the library's preferred size, ~17 KiB per point up to 8.8 GB); with less
+        # the backward runs in more, smaller chunks (include/emap_hip.h)
+        self.backward_workspace_limit = None
         self._scratch = {}
         self._err = None
 

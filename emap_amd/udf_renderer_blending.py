@@ -241,11 +241,13 @@ class UDFRendererBlending:
         with _lib.on_device(call["ro"]):
             nb = C.c_size_t()
             _lib.check(L.emap_render_bwd_workspace_bytes(C.byref(cfg), prec, C.byref(p), C.byref(nb)), "render_bwd_workspace_bytes")
-            ws = _workspace(self._bws, (N, S, prec), nb.value, dev)
+            lim = net.backward_workspace_limit
+            ws = _workspace(self._bws, (N, S, prec), nb.value if lim is None else min(nb.value, int(lim)), dev)
             _lib.check(L.emap_render_bwd_staged(C.byref(cfg), _lib.ptr(net.packed(call["prec_name"])), prec, C.byref(p),
                                                 _lib.ptr(call["ro"]), _lib.ptr(call["rd"]), _lib.ptr(call["ds"]), _lib.ptr(v["z_vals"]),
                                                 _lib.ptr(v["udf"]), _lib.ptr(v["gradients"]), _lib.ptr(v.get("_sd", v["_ws"])), C.byref(cg), C.byref(pg),
-                                                _lib.ptr(ws), ws.numel(), _lib.ptr(self._err), _lib.stream_ptr(dev), int(stages)),
+                                                _lib.ptr(ws), ws.numel() if lim is None else min(ws.numel(), int(lim)), _lib.ptr(self._err),
+                                                _lib.stream_ptr(dev), int(stages)),
                        "render_bwd")
         return flat
 
@@ -261,7 +263,8 @@ class UDFRendererBlending:
         nb, off = C.c_size_t(), C.c_size_t()
         _lib.check(L.emap_render_bwd_workspace_bytes(C.byref(cfg), prec, C.byref(p), C.byref(nb)), "render_bwd_workspace_bytes")
         _lib.check(L.emap_render_bwd_absmax_offset(C.byref(cfg), prec, C.byref(p), C.byref(off)), "render_bwd_absmax_offset")
-        ws = _workspace(self._bws, (N, S, prec), nb.value, dev)
+        lim = self.udf_network.backward_workspace_limit
+        ws = _workspace(self._bws, (N, S, prec), nb.value if lim is None else min(nb.value, int(lim)), dev)
         return ws[off.value:off.value + 8].view(torch.float32)
 
     def _trainable(self):

@@ -228,6 +228,10 @@ int emap_composite_bwd(const float* rays_o, const float* rays_d, const float* z,
                        const float* depth_scale, int N, int S, const float* sample_dist_dev, const EmapRenderParams* p,
                        const EmapCompositeGrads* g, float* d_udf, float* d_grad3, float* partials, void* stream);
 
+/* Workspace of the two backward entry points: *_workspace_bytes() is the PREFERRED size - the stash of the weight-gradient operands,
+ * ~17 KiB per point, for up to 524 288 points per launch of the sweep (8.8 GB; sized for 288 GB of HBM).  A caller may pass less: the
+ * backward then runs in more, smaller chunks (same results to the rounding of the partial sums; never fewer than 8 192 points
+ * per chunk, else EMAP_E_WORKSPACE with the minimum in emap_last_error()). */
 int emap_udf_vjp_workspace_bytes(const EmapNetConfig* cfg, int prec, int64_t P, size_t* bytes);
 int emap_udf_vjp(const EmapNetConfig* cfg, const void* packed, int prec, const float* x, int64_t P, const float* d_udf,
                  const float* d_grad3, const EmapParamGrads* out, void* workspace, size_t workspace_bytes,

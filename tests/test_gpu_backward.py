@@ -46,7 +46,8 @@ def _hip_vjp(net, x, du, dg):
     P = x.shape[0]
     nb = C.c_size_t()
     _lib.check(L.emap_udf_vjp_workspace_bytes(C.byref(cfg), prec, P, C.byref(nb)))
-    ws = torch.empty(nb.value, dtype=torch.uint8, device=DEV)
+    lim = getattr(net, "backward_workspace_limit", None)       # a caller may bound the workspace: more, smaller chunks (emap_hip.h)
+    ws = torch.empty(nb.value if lim is None else min(nb.value, int(lim)), dtype=torch.uint8, device=DEV)
     err = torch.zeros(1, dtype=torch.int32, device=DEV)
     x, du, dg = x.to(DEV).contiguous(), du.to(DEV).contiguous(), dg.to(DEV).contiguous()
     _lib.check(L.emap_udf_vjp(C.byref(cfg), _lib.ptr(net.packed()), prec, _lib.ptr(x), P, _lib.ptr(du), _lib.ptr(dg), C.byref(pg),
@@ -113,9 +114,10 @@ def test_udf_vjp_ragged_sizes(P):
 
 
 def test_udf_vjp_multi_chunk_and_linearity():
-    """More points than one sweep launch holds (the stash is bounded: 2048 tiles per chunk) and the size-independent
-    properties: linear in (du, dg), additive over point sets, deterministic."""
+    """More points than one sweep launch holds (here because the caller bounds the workspace: three chunks; the preferred workspace
+    holds 524 288 points) and the size-independent properties: linear in (du, dg), additive over point sets, deterministic."""
     net, state, cfg = mk("d8w256L10", "f16x3")
+    net.backward_workspace_limit = 700 << 20       # ~0.54 MiB of stash per 32-point tile: chunks of ~1100 tiles
     gen = torch.Generator().manual_seed(3)
     P = 2048 * 32 + 5000
     x = torch.rand(P, 3, generator=gen) * 2 - 1
@@ -133,6 +135,12 @@ def test_udf_vjp_multi_chunk_and_linearity():
     idx = torch.arange(0, P, 97)
     ref = _mirror_param_grads(state, cfg, x, du, dg)
     _cmp(a, ref, 1e-3, "vs mirror")
+    net.backward_workspace_limit = None            # one chunk: the same sums in another association
+    one = _hip_vjp(net, x, du, dg)
+    _cmp(one, {k: v.double() for k, v in a.items()}, 2e-4, "three chunks vs one")
+    net.backward_workspace_limit = 64 << 20        # less than the 256-tile minimum: the library refuses, it does not fall back
+    with pytest.raises(RuntimeError, match="workspace"):
+        _hip_vjp(net, x, du, dg)
 
 
 @pytest.mark.parametrize("case,car,fs,bg", [("c64_64_4", 1.0, 0.9, None), ("c64_50_5", 0.3, 0.0, 0.25), ("c32_32_4_small", None, 0.5, None)])
