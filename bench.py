@@ -442,7 +442,7 @@ def main():
         _lib.check(L.emap_profile_read_kernel(2, C.byref(wms), C.byref(wn)))
         bwd_us = {"udf_mlp_vjp_us_per_step": kms.value * 1e3 / n_prof, "wgrad_us_per_step": wms.value * 1e3 / n_prof,
                   "launches_per_step": [max(kn.value, 1) / n_prof, max(wn.value, 1) / n_prof]}
-    launches_per_step = max(kn.value, 1) / n_prof      # > 1 when the backward sweep runs in chunks of 65 536 points (> 512 rays per GPU)
+    launches_per_step = max(kn.value, 1) / n_prof      # > 1 when the backward sweep runs in chunks (> 524 288 points per GPU, or a bounded workspace)
     loss_now = trainer.last_stats.tolist() if trainer is not None else None
 
     if rank == 0:
@@ -506,9 +506,9 @@ def main():
         if os.path.exists(tpath):
             try:
                 ent = json.load(open(tpath)).get(f"{a.mode}:{a.precision}")
-                # the counters were collected on launches of 65 536 points (512 rays x 128 samples; the backward sweep runs in chunks
-                # of that size whatever the batch): no figure is quoted for a launch of another size
-                same_launch = (rays * S == 65536) if a.mode == "render" else (rays * S >= 65536 and (rays * S) % 65536 == 0)
+                # the counters were collected on launches of 65 536 points (512 rays x 128 samples): no figure is quoted for a launch of
+                # another size (the backward sweep runs in one launch up to 524 288 points)
+                same_launch = rays * S == 65536
                 if ent and same_launch:
                     line["roofline"]["traffic"] = ent["hbm_bytes_per_launch"]
                     line["roofline"]["traffic_source"] = ("STATIC: profiles/r03_traffic.json, recorded by rocprofv3 --pmc passes of this kernel at this launch "
