@@ -61,6 +61,9 @@ def gemm(W, x, passes):
         return z + (xl @ Wh.T) / LO
     if passes == "hh+hl+lh":
         return z + (xl @ Wh.T + xh @ Wl.T) / LO
+    if passes in ("hh+hl+l8h", "hh+hl+l8bh"):      # only the weights' lo part stored as e4m3 (fixed scale / per-32 block scale); activations stay f16 hi + lo
+        blk = 32 if passes.endswith("bh") else None
+        return z + (xl @ Wh.T + xh @ q8(Wl, blk).T) / LO
     if passes in ("hh+x8", "hh+x8b"):
         blk = 32 if passes.endswith("b") else None
         return z + (q8(xl, blk) @ q8(Wh, blk).T + q8(xh, blk) @ q8(Wl, blk).T) / LO
@@ -137,7 +140,7 @@ def main():
     rel = lambda a, b: float((a.double() - b).abs().max() / b.abs().max())
     variants = [("hh+hl+lh", "hh+hl+lh"), ("hh+hl+lh", "hh+lh"), ("hh+hl+lh", "hh+hl"), ("hh+hl+lh", "hh"),
                 ("hh+x8", "hh+x8"), ("hh+x8b", "hh+x8b"), ("hh+hl+lh", "hh+x8"), ("hh+x8", "hh"), ("hh+x8b", "hh"),
-                ("hh+lh", "hh+lh"), ("hh", "hh")]
+                ("hh+lh", "hh+lh"), ("hh", "hh"), ("hh+hl+l8h", "hh+hl+l8h"), ("hh+hl+l8bh", "hh+hl+l8bh")]
     for fwd, bwd in variants:
         u, g = emulate(state, cfg, xg, fwd, bwd)
         ur, gr = emulate(state, cfg, xr, fwd, bwd)
