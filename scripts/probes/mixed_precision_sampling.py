@@ -47,7 +47,7 @@ def main():
     orig = O.udf_value
     ref = O.render(state, cfg, rcfg, ro, rd, near, far, ds, var, bp, gp, **kwargs)
     rel = lambda a, b: float((a.double() - b.double()).abs().max() / b.double().abs().max())
-    for passes in ("hh+hl+lh", "hh+lh", "hh"):
+    for passes in ("hh+hl+lh", "hh+hl+l8h", "hh+lh", "hh"):
         calls = {"n": 0}
 
         def patched(st, c, x, _p=passes):
