@@ -289,3 +289,10 @@ def test_extraction_chunking_policy():
     assert not E._uses_package_net(foreign) and not E._uses_package_net(len)
     assert E._chunk(net.udf, closure, 4096) == E._BIG == 1 << 20
     assert E._chunk(net.udf, foreign, 4096) == 4096 and E._chunk(foreign, foreign, 128, 50) == 6400
+
+
+def test_graft_entry_verifies_the_prebuilt_library():
+    """__graft_entry__.build() ends with verify_library(): the freshly loaded libemap_hip.so must carry the ABI version of emap_amd/_lib.py
+    (the compile itself - minutes - is the driver's check; this is the part that can silently go stale)."""
+    import __graft_entry__ as g
+    g.verify_library()
