@@ -143,6 +143,28 @@ def test_udf_vjp_multi_chunk_and_linearity():
         _hip_vjp(net, x, du, dg)
 
 
+def test_udf_vjp_beyond_the_preferred_chunk():
+    """More points than the preferred workspace holds in one launch of the sweep (16 384 tiles = 524 288 points; 8.8 GB of stash): the library
+    itself splits the backward.  Size-independent properties only (the CPU mirror would take minutes): run-to-run identical, additive over the
+    two point sets the chunk boundary separates, exactly homogeneous under a power-of-two scaling of (du, dg)."""
+    net, state, cfg = mk("d8w256L10", "f16x3")
+    gen = torch.Generator().manual_seed(5)
+    h = 16384 * 32
+    P = h + 40000
+    x = torch.rand(P, 3, generator=gen) * 2 - 1
+    du = torch.randn(P, generator=gen) * 1e-3
+    dg = torch.randn(P, 3, generator=gen) * 1e-4
+    a = _hip_vjp(net, x, du, dg)
+    a2 = _hip_vjp(net, x, du, dg)
+    assert all(torch.equal(a[k], a2[k]) for k in a), "two identical launches differ"
+    assert all(bool(torch.isfinite(v).all()) for v in a.values())
+    b1 = _hip_vjp(net, x[:h], du[:h], dg[:h])
+    b2 = _hip_vjp(net, x[h:], du[h:], dg[h:])
+    _cmp({k: b1[k] + b2[k] for k in a}, {k: v.double() for k, v in a.items()}, 2e-4, "additivity across the chunk boundary")
+    c = _hip_vjp(net, x, du * 8, dg * 8)
+    _cmp({k: c[k] / 8 for k in a}, {k: v.double() for k, v in a.items()}, 1e-6, "homogeneity")
+
+
 @pytest.mark.parametrize("case,car,fs,bg", [("c64_64_4", 1.0, 0.9, None), ("c64_50_5", 0.3, 0.0, 0.25), ("c32_32_4_small", None, 0.5, None)])
 def test_composite_bwd_vs_mirror(case, car, fs, bg):
     g = load_golden("g5_render_" + case)
