@@ -127,6 +127,9 @@ __device__ __forceinline__ void wgrad_store(const WgradArgs& a, const WgradJob& 
 // steps in flight (no registers are involved, so nothing the compiler could copy: loads stay in flight across the loop
 // back-edge); per step: s_waitcnt vmcnt (my fragments of this step have landed) -> s_barrier (everyone's have, and everyone
 // has finished reading the stage about to be refilled) -> issue step u + D -> 18 ds_read_b128 + 32 MFMAs.
+#ifndef EMAP_REDUCE_WAVES
+#define EMAP_REDUCE_WAVES 4
+#endif
 #ifndef EMAP_WGRAD_DEPTH
 #define EMAP_WGRAD_DEPTH 3
 #endif
@@ -269,10 +272,11 @@ __device__ __forceinline__ float wave_sum_f(float v) {
 
 // 4 consecutive output rows per wave: they are the 4 accumulator registers of one lane of the MFMA output, i.e. ONE 16-byte
 // word of the partial blocks per (column, slice) - every load is a float4 and a wave reads 256-byte runs.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const ReduceArgs a) {
+constexpr int RED_WAVES = EMAP_REDUCE_WAVES;   // waves of a row group: each sums every RED_WAVES-th K-slice
+__global__ __launch_bounds__(RED_WAVES * 64) void wgrad_reduce_kernel(const ReduceArgs a) {
     // one workgroup per group of 4 rows: its 4 waves each sum every 4th K-slice (there are only ~500 groups: with one wave per group
     // the kernel was a latency chain on two waves per CU), wave 0 adds the four partial sums in a fixed order and finishes the rows
-    __shared__ f32x4 part[3][6][64];
+    __shared__ f32x4 part[RED_WAVES - 1][6][64];
     const int grp = blockIdx.x;
     const int wv = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
@@ -327,7 +331,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const ReduceArgs a) {
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) sum[c] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
-    for (int q = wv; q < nmax; q += 4) {       // fixed order per column and wave: deterministic
+    for (int q = wv; q < nmax; q += RED_WAVES) {       // fixed order per column and wave: deterministic
         f32x4 v[MAXC];
 #pragma unroll
         for (int c = 0; c < MAXC; ++c)         // unconditional loads (a column with fewer slices re-reads its last one): they issue as one batch
@@ -345,7 +349,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const ReduceArgs a) {
     __syncthreads();
     if (wv > 0) return;
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) sum[c] += (part[0][c][lane] + part[1][c][lane]) + part[2][c][lane];
+    for (int c = 0; c < MAXC; ++c) {
+        f32x4 t = part[0][c][lane];
+#pragma unroll
+        for (int w = 1; w < RED_WAVES - 1; ++w) t += part[w][c][lane];      // fixed order
+        sum[c] += t;
+    }
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
         const int k = lane + 64 * c;
@@ -370,6 +379,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const ReduceArgs a) {
     if (last && a.weight_norm && a.g[l][0] != 0.f) {
         // exact component of dW along W: dot(dW, v) = (||v||/g) sum_tiles ldot  (fixed order: deterministic)
         float ld = 0.f;
+#pragma unroll 8
         for (int t = lane; t < a.n_tiles; t += 64) ld += a.ldot[t];
         ld = wave_sum_f(ld);
         dot[0] = ld * inv_k * sqrtf(nrm[0]) / a.g[l][0];
@@ -399,14 +409,21 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const ReduceArgs a) {
             }
         }
     }
-    if (lane < 4 && o0 + lane < out_dim) {
-        const int o = o0 + lane;
+    {   // bias rows: 16 lanes per row, lane i sums the K-slices q = i, i + 16, ... in order, then a fixed tree over the 16 lanes (deterministic;
+        // one lane per row walking all slices was a chain of ~28 dependent global loads in every workgroup)
+        const int r = lane >> 4, i = lane & 15;
+        const int o = o0 + r;
         const int jb = (a.job_h[l] >= 0) ? a.job_h[l] : a.job_pe[l];
         const WgradJob& J = a.job[jb];
         float s = 0.f;
-        for (int q = 0; q < J.n_slices; ++q) s += a.partial[J.bias_off + (size_t)q * 256 + o] + (last ? a.partial[J.bias_off + (size_t)q * 256 + 1] : 0.f);
-        const float x = s * inv_k;
-        a.db[l][o] = a.accumulate ? a.db[l][o] + x : x;
+        if (o < out_dim)
+            for (int q = i; q < J.n_slices; q += 16) s += a.partial[J.bias_off + (size_t)q * 256 + o] + (last ? a.partial[J.bias_off + (size_t)q * 256 + 1] : 0.f);
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off);
+        if (i == 0 && o < out_dim) {
+            const float x = s * inv_k;
+            a.db[l][o] = a.accumulate ? a.db[l][o] + x : x;
+        }
     }
 }
 
@@ -521,7 +538,7 @@ int launch_wgrad_reduce(const NetLayout& L, const WgradJob* jobs, int n_jobs, co
     }
     a.row_off[L.n_lin] = rows;
     for (int i = 0; i < n_jobs; ++i) a.job[i] = jobs[i];
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rows), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rows), dim3(RED_WAVES * 64), 0, st, a);
     return check_launch("wgrad_reduce");
 }
 
