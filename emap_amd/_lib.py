@@ -21,7 +21,7 @@ PREC_F16X3 = 3
 PRECISIONS = {"bf16": PREC_BF16, "bf16x3": PREC_BF16X3, "f16": PREC_F16, "f16x3": PREC_F16X3}
 UDF_TYPES = {"abs": 0, "square": 1, "sdf": 2}
 MAX_LIN = 12
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 F_NAN_SAMPLES = 1
 F_NAN_GRADERR = 2
@@ -75,6 +75,7 @@ _P = C.c_void_p
 SYMBOLS = {
     "emap_abi_version": (C.c_int, []),
     "emap_last_error": (C.c_char_p, []),
+    "emap_set_grad_mode": (C.c_int, [C.c_int]),
     "emap_packed_bytes": (C.c_int, [C.POINTER(NetConfig), C.c_int, C.POINTER(C.c_size_t)]),
     "emap_pack_weights": (C.c_int, [C.POINTER(NetConfig), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), _P, C.c_int, _P]),
     "emap_udf_fwd": (C.c_int, [C.POINTER(NetConfig), _P, C.c_int, _P, C.c_int64, _P, _P]),

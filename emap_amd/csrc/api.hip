@@ -208,6 +208,7 @@ extern "C" {
 
 int emap_abi_version(void) { return EMAP_ABI_VERSION; }
 const char* emap_last_error(void) { return g_err; }
+int emap_set_grad_mode(int mode) { return set_grad_mode(mode); }
 
 int emap_packed_bytes(const EmapNetConfig* cfg, int prec, size_t* bytes) {
     NetLayout L;
@@ -572,7 +573,11 @@ int emap_profile_enable(int on) {
     if (on) for (int k = 0; k < PROF_KERNELS; ++k) g_prof_n[k] = 0;
     // shader-clock stamps of the two big MLP kernels (udf_mlp_kernel.inc:clock_stamp): a device buffer on the current device while
     // profiling is on; the launchers pass null otherwise
+    int cur_dev = -1;
+    if (on && hipGetDevice(&cur_dev) != hipSuccess) { set_error("hipGetDevice failed"); return EMAP_E_LAUNCH; }
+    if (on && g_clk_dev && cur_dev != emap::g_prof_clk_device) { (void)hipFree(g_clk_dev); g_clk_dev = nullptr; }   // profiling moved to another device
     if (on && !g_clk_dev) {
+        emap::g_prof_clk_device = cur_dev;
         if (hipMalloc(reinterpret_cast<void**>(&g_clk_dev), 8 * sizeof(long long)) != hipSuccess) { g_clk_dev = nullptr; set_error("hipMalloc failed"); return EMAP_E_LAUNCH; }
     }
     if (on && hipMemset(g_clk_dev, 0, 8 * sizeof(long long)) != hipSuccess) { set_error("hipMemset failed"); return EMAP_E_LAUNCH; }

@@ -154,6 +154,9 @@ struct WgradJob {
 
 
 bool mlp_uses_rev(const NetLayout& L, int prec, int64_t P);
+int set_grad_mode(int mode);   // -1 by launch size, 0 forward-mode tangents, 1 reverse sweep; returns the previous setting (udf_mlp.hip)
+extern int g_prof_clk_device;
+long long* prof_clk_here();   // g_prof_clk if the current device is the one it was allocated on, else null
 extern long long* g_prof_clk;   // device buffer of 8 x int64 while emap_profile_enable(1) is in effect, else null (clock_stamp in udf_mlp_kernel.inc)
 constexpr int REV_MAX_WG = 768;      // persistent workgroups of the reverse-mode kernel (3 per CU)
 inline size_t rev_scratch_bytes(const NetLayout& L) {   // sigmoid stash: [workgroup][layer][pair][4][64 lanes x 16 B]

@@ -7,11 +7,18 @@
 
 namespace emap {
 long long* g_prof_clk = nullptr;
+int g_prof_clk_device = -1;
+// the clock buffer lives on the device that was current when profiling was enabled: launches on another device of the process get
+// no stamps (a foreign device pointer would fault without peer access)
+long long* prof_clk_here() {
+    if (!g_prof_clk) return nullptr;
+    int d = -1;
+    return (hipGetDevice(&d) == hipSuccess && d == g_prof_clk_device) ? g_prof_clk : nullptr;
+}
 
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-constexpr int MAX_CHUNKS = 96;   // EMAP_MAX_LIN * 8 pairs
 __host__ __device__ constexpr bool prec_is_f16(int mode) { return mode == EMAP_PREC_F16 || mode == EMAP_PREC_F16X3; }
 __host__ __device__ constexpr int prec_nparts(int mode) { return (mode == EMAP_PREC_BF16 || mode == EMAP_PREC_F16) ? 1 : 2; }
 
@@ -346,7 +353,7 @@ int build_layout(const EmapNetConfig* cfg, int prec, NetLayout* L) {
     L->bias_off_bytes = 0;
     L->rowscale_off_bytes = cfg->n_lin * H * 4;
     L->frag_off_bytes = ((2 * cfg->n_lin * H * 4 + 1023) / 1024) * 1024;
-    if (chunks > MAX_CHUNKS || frag > 65535) { set_error("network too large for the chunk table"); return EMAP_E_INVALID; }
+    if (frag > 65535) { set_error("network too large for the fragment table"); return EMAP_E_INVALID; }
     // transposed section for the reverse sweep
     L->has_rev = (cfg->skip_l < cfg->n_lin - 1) ? 1 : 0;
     L->wlast_off_bytes = L->frag_off_bytes + frag * FRAG_BYTES;
@@ -414,24 +421,28 @@ int launch_mlp_bf16x3(const NetLayout&, const void*, const PointSource&, int64_t
 int launch_mlp_f16(const NetLayout&, const void*, const PointSource&, int64_t, float*, float*, hipStream_t, int, int32_t*, void*);
 int launch_mlp_f16x3(const NetLayout&, const void*, const PointSource&, int64_t, float*, float*, hipStream_t, int, int32_t*, void*);
 
-// kernel variant: 0 = "classic" (column-split waves, weights shared through LDS, one wave per SIMD),
-// 1 = "fs" (feature-split waves, one workgroup per CU), 2 = "fs2" (feature-split, two/three workgroups per CU),
-// 3 = "rev" (grad launches only: forward + reverse sweep on 32x32x16 MFMA tiles, udf_mlp_rev32.inc).
-// The library reads exactly two environment switches, per call: EMAP_MLP_KERNEL=classic|fs|fs2 forces one forward-mode variant,
-// EMAP_GRAD_MODE=fwd|rev picks how d(udf)/dx is computed (A/B measurements, tests); the precision mode is an API argument.
-static int mlp_variant(const NetLayout& L, int prec, int64_t P, bool grad) {
-    // read on every call (two getenv, ~100 ns): the tests and the A/B scripts flip them inside one process
-    const char* e = getenv("EMAP_MLP_KERNEL");
-    const int forced = !e ? -1 : (!strcmp(e, "classic") ? 0 : (!strcmp(e, "fs") ? 1 : (!strcmp(e, "fs2") ? 2 : -1)));
+// kernel variant: 2 = "fs2" (udf_mlp_fs2_kernel: every value launch, forward-mode tangents for small grad launches),
+// 3 = "rev" (grad launches only: forward + reverse sweep on 32x32 MFMA tiles, udf_mlp_rev32.inc).
+// How d(udf)/dx is computed is a process-wide setting (emap_set_grad_mode; -1 = by launch size, 0 = always forward-mode tangents,
+// 1 = always the reverse sweep), initialised ONCE at library load from EMAP_GRAD_MODE=fwd|rev: no getenv on the launch path
+// (rounds 1-3 read two environment variables per launch).
+static int grad_mode_from_env() {
     const char* gm = getenv("EMAP_GRAD_MODE");
-    const int grad_mode = !gm ? -1 : (!strcmp(gm, "fwd") ? 0 : (!strcmp(gm, "rev") ? 1 : -1));
+    return !gm ? -1 : (!strcmp(gm, "fwd") ? 0 : (!strcmp(gm, "rev") ? 1 : -1));
+}
+static int g_grad_mode = grad_mode_from_env();
+int set_grad_mode(int mode) {
+    const int old = g_grad_mode;
+    g_grad_mode = (mode == 0 || mode == 1) ? mode : -1;
+    return old;
+}
+static int mlp_variant(const NetLayout& L, int prec, int64_t P, bool grad) {
     // reverse mode halves the MFMA work of a grad launch but a tile is two dependent sweeps: it wins once most CUs have a
     // workgroup (measured crossover: the split modes between 8k and 12k points, single-pass modes at 16k).
     const int64_t rev_min = (prec == EMAP_PREC_F16X3 || prec == EMAP_PREC_BF16X3) ? 10240 : 16384;
-    if (grad && L.has_rev && forced < 0 && grad_mode != 0 && (P >= rev_min || grad_mode >= 1)) return 3;
-    if (forced >= 0) return forced;
-    (void)prec; (void)P;
-    return 2;   // fs2 (two or three workgroups per CU) measured fastest or equal at every size and mode on MI355X
+    const int gm = g_grad_mode;
+    if (grad && L.has_rev && gm != 0 && (P >= rev_min || gm == 1)) return 3;
+    return 2;
 }
 
 bool mlp_uses_rev(const NetLayout& L, int prec, int64_t P) { return mlp_variant(L, prec, P, true) == 3; }

@@ -4,9 +4,7 @@ namespace emap {
 int launch_mlp_f16(const NetLayout& L, const void* packed, const PointSource& src, int64_t P, float* udf, float* grad3,
                       hipStream_t st, int variant, int32_t* err, void* scratch) {
     if (variant == 3) return launch_mlp_rev32_mode<EMAP_PREC_F16>(L, packed, src, P, udf, grad3, st, err, scratch);
-    if (variant == 2) return launch_mlp_fs2_mode<EMAP_PREC_F16>(L, packed, src, P, udf, grad3, st, err);
-    if (variant == 1) return launch_mlp_fs_mode<EMAP_PREC_F16>(L, packed, src, P, udf, grad3, st, err);
-    return launch_mlp_mode<EMAP_PREC_F16>(L, packed, src, P, udf, grad3, st, err);
+    return launch_mlp_fs2_mode<EMAP_PREC_F16>(L, packed, src, P, udf, grad3, st, err);
 }
 int launch_vjp_sweep_f16(const NetLayout& L, const void* packed, const PointSource& src, int64_t P, int tile0, int n_tiles,
                             const float* d_udf, const float* d_grad, const VjpLayout& V, char* stash_a, char* stash_z, char* stash_s,

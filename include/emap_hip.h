@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EMAP_ABI_VERSION 5
+#define EMAP_ABI_VERSION 6
 
 /* error codes */
 #define EMAP_OK 0
@@ -67,6 +67,12 @@ typedef struct EmapNetConfig {
 
 int emap_abi_version(void);
 const char* emap_last_error(void);
+
+/* How UDFNetwork.gradient (udf_model.py:121-135) is evaluated, process-wide: -1 (default) = by launch size (reverse sweep from
+ * 10 240 points in the split modes / 16 384 in the single-pass modes, forward-mode tangents below), 0 = always forward-mode tangents,
+ * 1 = always the reverse sweep.  Read ONCE at library load from EMAP_GRAD_MODE=fwd|rev; this call changes it afterwards (tests, A/B
+ * measurements).  Returns the previous setting.  Not a per-launch environment lookup any more (ABI 6). */
+int emap_set_grad_mode(int mode);
 
 /* ---- weights -------------------------------------------------------------------------------
  * Replaces the per-call weight_norm re-evaluation of nn.utils.parametrizations.weight_norm

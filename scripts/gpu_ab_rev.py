@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Same-box A/B of the value + grad_x MLP kernels: EMAP_GRAD_MODE in {rev (reverse sweep, 32x32x16 tiles), fwd (forward-mode tangents)};
+"""Same-box A/B of the value + grad_x MLP kernels: emap_set_grad_mode in {rev (reverse sweep, 32x32x16 tiles), fwd (forward-mode tangents)};
 EMAP_HIP_LIB selects another build of the library (scripts/build_variant.sh) for A/B of kernel changes.
 
-Interleaved rounds in ONE process (the env switch is re-read per call), HIP-event medians, and the agreement of every variant
+Interleaved rounds in ONE process (emap_set_grad_mode between the calls), HIP-event medians, and the agreement of every variant
 with the fp64 CPU oracle on the same points (sizes the oracle finishes in seconds) and with the reference golden g2.
 
     python scripts/gpu_ab_rev.py [f16x3 bf16x3 ...] [--points 65536] [--rounds 15]
@@ -50,7 +50,7 @@ def main():
         res = {}
         with torch.no_grad():
             for v in variants:
-                os.environ["EMAP_GRAD_MODE"] = v
+                emap_amd._lib.lib().emap_set_grad_mode({"fwd": 0, "rev": 1}[v])
                 u, g = net.hip_udf(xd, with_grad=True)
                 torch.cuda.synchronize()
                 res[v] = (u.clone(), g.clone())
@@ -67,13 +67,13 @@ def main():
             # interleaved timing
             times = {v: [] for v in variants}
             for v in variants:                      # warm-up
-                os.environ["EMAP_GRAD_MODE"] = v
+                emap_amd._lib.lib().emap_set_grad_mode({"fwd": 0, "rev": 1}[v])
                 for _ in range(3):
                     net.hip_udf(xd, with_grad=True)
             torch.cuda.synchronize()
             for _ in range(args.rounds):
                 for v in variants:
-                    os.environ["EMAP_GRAD_MODE"] = v
+                    emap_amd._lib.lib().emap_set_grad_mode({"fwd": 0, "rev": 1}[v])
                     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     s.record()
                     for _ in range(4):
@@ -85,7 +85,7 @@ def main():
                 t = sorted(times[v])
                 out[v]["us_median"] = round(t[len(t) // 2], 1)
                 out[v]["us_min"] = round(t[0], 1)
-        os.environ.pop("EMAP_GRAD_MODE", None)
+        emap_amd._lib.lib().emap_set_grad_mode(-1)
         print(json.dumps(out))
 
 
