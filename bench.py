@@ -59,6 +59,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--mode", default="render", choices=["render", "train"])
+    ap.add_argument("--path", default="native", choices=["native", "dropin", "dropin-fused"],
+                    help="train mode, one GPU: native = emap_amd.parallel.Trainer (flat buffers, fused Adam); dropin = the reference runner's own "
+                         "step on the drop-in classes (autograd, torch.optim.Adam, .item() reads); dropin-fused = the same with emap_amd's FusedAdam")
     ap.add_argument("--rays", type=int, default=512, help="rays per GPU (weak scaling)")
     ap.add_argument("--global-rays", type=int, default=0, help="rays of the GLOBAL batch, split over the ranks (strong scaling)")
     ap.add_argument("--precision", default=os.environ.get("EMAP_BENCH_PRECISION", "f16x3"), choices=list(MODE_DTYPE),
@@ -187,6 +190,130 @@ def train_key(dev, precision, rays, S, steps=40, warmup=10):
         except Exception:
             pass
     return out
+
+
+def _timed(fn, steps, warmup):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for s_ev, e_ev in evs:
+        s_ev.record()
+        fn()
+        e_ev.record()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return dt, sorted(s_ev.elapsed_time(e_ev) for s_ev, e_ev in evs)[steps // 2]
+
+
+def train_dropin_key(dev, precision, rays, steps=40, warmup=10, n_samples=64, n_importance=64, up_sample_steps=4, fused_adam=False):
+    """The optimizer step AS THE REFERENCE'S RUNNER TAKES IT (src/runner/runner_udf.py:63-168 with runner_base.py:96-126) on the
+    classes `emap_amd.dropin.install()` puts under `src.models.*`: the dataset's ray draw (the device sampler the drop-in patches
+    in), `renderer.render()` under autograd (RenderFn), EdgeLoss, the runner's loss assembly with its host reads
+    (`beta.item()`, `loss.item()`), `loss.backward()`, `torch.optim.Adam` over the runner's parameter groups (27 + 5 tensors).
+    The runner module itself needs pyhocon / cv2 / tensorboard (absent here), so its loop body is restated on those classes."""
+    import emap_amd
+    from emap_amd import dropin, synthetic
+    dropin.install()
+    from src.models.udf_model import UDFNetwork, SingleVarianceNetwork, BetaNetwork      # = emap_amd's, through the aliases
+    from src.models.udf_renderer_blending import UDFRendererBlending
+    from src.models.loss import EdgeLoss
+    kw = dict(d_in=3, d_out=1, d_hidden=256, n_layers=8, skip_in=(4,), multires=10, bias=0.5)
+    udf_network = UDFNetwork(scale=1.0, **kw)
+    udf_network.load_state_dict(synthetic.make_udf_state(seed=42, pert=0.02, **kw))
+    udf_network = udf_network.to(dev)
+    udf_network.precision = precision
+    variance_network = SingleVarianceNetwork(0.3).to(dev)
+    beta_network = BetaNetwork(0.5, 0.3, 0.3, 5e-5, True, True, False).to(dev)
+    lr, lr_geo = 5e-4, 1e-4
+    if fused_adam:
+        from emap_amd.parallel import FusedAdam
+        optimizer = FusedAdam([{"params": list(udf_network.parameters()), "lr": lr_geo},
+                               {"params": list(variance_network.parameters()) + list(beta_network.parameters())}], lr=lr)
+    else:
+        optimizer = torch.optim.Adam([{"params": list(udf_network.parameters()), "lr": lr_geo},
+                                      {"params": list(variance_network.parameters()) + list(beta_network.parameters())},
+                                      {"params": []}], lr=lr)
+    renderer = UDFRendererBlending(None, udf_network, variance_network, beta_network, n_samples=n_samples, n_importance=n_importance,
+                                   n_outside=0, up_sample_steps=up_sample_steps, perturb=1.0, device=dev)
+    edge_loss_func = EdgeLoss("mse")
+    meta, edges = synthetic.make_scene(n_images=8, H=400, W=400, seed=3)
+    sampler = emap_amd.DeviceRaySampler.from_meta(meta, edges, device=dev, seed=1000)
+    near, far = float(meta["scene_box"]["near"]), float(meta["scene_box"]["far"])
+    edge_weight, igr_weight, igr_ns_weight = 1.0, 0.1, 0.0
+    state = {"iter": 0, "beta_flag": True, "loss": None}
+    image_perm = list(range(8))
+
+    def step():
+        it = state["iter"]
+        for g_, base in zip(optimizer.param_groups, (lr_geo, lr, lr)):      # update_learning_rate (runner_base.py:128-161): warm-up ramp
+            g_["lr"] = base * min(1.0, (it + 1) / 1000.0)
+        smp = sampler.gen_random_rays_patches_at(image_perm[it % len(image_perm)], rays, importance_sample=True)
+        data = smp["rays"]
+        rays_o, rays_d, true_edge = data["rays_o"], data["rays_v"], data["edge"]
+        mask = torch.ones_like(true_edge).float()
+        mask_sum = mask.sum() + 1e-5
+        out = renderer.render(rays_o, rays_d, near, far, depth_scale=smp["depth_scale"], flip_saturation=0.9, pose=None, fx=None, fy=None,
+                              img_index=None, cos_anneal_ratio=1.0)
+        udf, edge = out["udf"], out["edge"]
+        variance, beta = out["variance"], out["beta"]
+        udf_min = udf.min(dim=1)[0][mask[:, 0] > 0.5].mean()                   # noqa: F841  (the runner computes it for its log)
+        edge_loss = edge_loss_func(edge, true_edge) * edge_weight
+        psnr = 20.0 * torch.log10(1.0 / (((edge - true_edge) ** 2 * mask).sum() / mask_sum).sqrt())   # noqa: F841
+        if variance.mean() < 2 * beta.item() and variance.mean() < 0.01 and state["beta_flag"] and variance_network.variance.requires_grad:
+            beta_network.set_beta_trainable()
+            state["beta_flag"] = False
+        if variance_network.variance.requires_grad is False and it > 20000:
+            variance_network.set_trainable()
+        loss = edge_loss + out["gradient_error_near_surface"] * igr_ns_weight + out["gradient_error"] * igr_weight
+        state["loss"] = loss.item()                                            # the progress-bar read of runner_udf.py:164
+        optimizer.zero_grad()
+        loss.backward()
+        optimizer.step()
+        state["iter"] = it + 1
+
+    S = renderer.samples_per_ray
+    dt, med = _timed(step, steps, warmup)
+    renderer.check_errors()
+    return {"metric": "ray-samples/sec (the reference runner's own step on the drop-in classes: autograd render + EdgeLoss + .item() reads + "
+                      + ("emap_amd FusedAdam" if fused_adam else "torch.optim.Adam") + ")",
+            "rays": rays, "samples_per_ray": S, "steps": steps, "warmup": warmup, "ms_per_step": dt * 1e3, "ms_per_step_median": med,
+            "value": rays * S / dt, "unit": "ray-samples/s", "host_syncs_per_step": 4, "loss_after_run": state["loss"],
+            "reference": "src/runner/runner_udf.py:63-168, runner_base.py:96-126"}
+
+
+def default_shape_key(dev, precision, steps=40, warmup=10):
+    """The launch shape of the reference's own configuration (confs/ABC.conf:31,108-111): batch_size 1024, n_samples 64,
+    n_importance 50, up_sample_steps 5 -> 64 + 5 x 10 = 114 samples per ray: forward render() and the native training step."""
+    import emap_amd
+    from emap_amd import synthetic
+    from emap_amd.parallel import Trainer
+    rays, S_c, S_f, K = 1024, 64, 50, 5
+    r, _, _ = build_renderer(dev, precision)
+    r = emap_amd.UDFRendererBlending(None, r.udf_network, r.deviation_network, r.beta_network, n_samples=S_c, n_importance=S_f, n_outside=0,
+                                     up_sample_steps=K, perturb=1.0, device=dev)
+    S = r.samples_per_ray
+    ro, rd, near, far, ds = [t.contiguous().to(dev) for t in synthetic.make_rays(rays, seed=1)]
+    tr = synthetic.make_t_rand(rays).to(dev)
+    te = synthetic.make_true_edge(rays, seed=11).to(dev)
+
+    def fwd():
+        with torch.no_grad():
+            return r.render(ro, rd, near, far, ds, cos_anneal_ratio=1.0, flip_saturation=0.9, t_rand=tr)
+    dt_f, med_f = _timed(fwd, steps, warmup)
+    trainer = Trainer(r, lr_geo=1e-4, lr=5e-4, edge_weight=1.0, igr_weight=0.1, igr_ns_weight=0.0)
+    batch = {"rays_o": ro, "rays_d": rd, "near": near, "far": far, "depth_scale": ds, "cos_anneal_ratio": 1.0, "flip_saturation": 0.9, "t_rand": tr}
+    dt_t, med_t = _timed(lambda: trainer.step(batch, te, n_rays_global=rays), steps, warmup)
+    r.check_errors()
+    e_ng = S_c + S_f * (K - 1) / K
+    a_fwd, a_train = F_POINT * (e_ng / S + 2), F_POINT * (e_ng / S + 6)
+    return {"workload": f"{rays} rays x {S} samples ({S_c} coarse + {S_f} fine in {K} up-sampling steps), confs/ABC.conf:31,108-111",
+            "rays": rays, "samples_per_ray": S, "steps": steps, "warmup": warmup,
+            "render": {"ms_per_step": dt_f * 1e3, "ms_per_step_median": med_f, "value": rays * S / dt_f, "unit": "ray-samples/s",
+                       "whole_step_frac_of_mfma_peak": rays * S / dt_f * a_fwd / 1e12 / MFMA_PEAK_TFLOPS, "launch": "eager"},
+            "train": {"ms_per_step": dt_t * 1e3, "ms_per_step_median": med_t, "value": rays * S / dt_t, "unit": "ray-samples/s",
+                      "whole_step_frac_of_mfma_peak": rays * S / dt_t * a_train / 1e12 / MFMA_PEAK_TFLOPS, "launch": "eager"}}
 
 
 def cpu_model():
@@ -548,6 +675,16 @@ def main():
                 line["train"] = train_key(dev, a.precision, rays, S)
             except Exception as e:   # the secondary measurement must never take the headline down
                 line["train"] = {"error": repr(e)}
+            try:    # the reference runner's own step through the drop-in classes
+                line["train_dropin"] = train_dropin_key(dev, a.precision, rays)
+                if isinstance(line.get("train"), dict) and line["train"].get("ms_per_step"):
+                    line["train_dropin"]["vs_native_trainer"] = line["train_dropin"]["ms_per_step"] / line["train"]["ms_per_step"]
+            except Exception as e:
+                line["train_dropin"] = {"error": repr(e)}
+            try:
+                line["reference_default_shape"] = default_shape_key(dev, a.precision)
+            except Exception as e:
+                line["reference_default_shape"] = {"error": repr(e)}
         if not a.no_cpu_baseline and world == 1:
             try:
                 line["cpu_baseline"] = cpu_baseline(state, kw, a.cpu_rays, a.mode)

@@ -72,6 +72,21 @@ struct NetLayout {
     LayerDesc layer[EMAP_MAX_LIN];
 };
 
+// The transposed 32x32 section in the MIXED layout of the MX-fp6 reverse sweep (udf_mlp.hip:pack32_t_body, udf_mlp_rev32.inc):
+// split-fp16 at d_hidden = 256 (a sweep wave owns two row tiles = one 32-value MX block per lane)
+#ifndef EMAP_REV_MX6
+#define EMAP_REV_MX6 1      // 0: f16 cross terms in the backward GEMMs too (A/B builds: compile udf_mlp AND udf_mlp_f16x3 with the flag)
+#endif
+__host__ __device__ inline bool r32_t_mixed(const NetLayout& L) { return EMAP_REV_MX6 && L.is_f16 && L.nparts == 2 && L.H == 256; }
+// E8M0 scale of an MX block of e2m3 values with largest magnitude m, as the exponent field of an fp32 (bits 23..30):
+// 2^(floor(log2(m * 8/7.5)) - 2), so that m / scale <= 7.5 (the e2m3 maximum)
+__host__ __device__ inline uint32_t mx6_scale_bits(float m) {
+    const float mm = fmaxf(m, 7.8886090522101181e-31f /* 2^-100 */) * 1.0666667f;
+    uint32_t b;
+    __builtin_memcpy(&b, &mm, 4);
+    return (b & 0x7f800000u) - (2u << 23);
+}
+
 // returns 0 or EMAP_E_INVALID (error text set)
 int build_layout(const EmapNetConfig* cfg, int prec, NetLayout* L);
 inline size_t layout_bytes(const NetLayout& L) {

@@ -254,6 +254,9 @@ __device__ __forceinline__ void pack32_body(const PackArgs& a, unsigned block) {
     store_frag(a, a.packed + a.L.r32_frag_off_bytes + F * FRAG_BYTES + lane * 16, w, part);
 }
 
+typedef _Float16 f16x32 __attribute__((ext_vector_type(32)));
+typedef uint32_t u32x6 __attribute__((ext_vector_type(6)));
+
 // Transposed fragments of the 32x32x16 reverse sweep: A operand of  delta_in = W_l^T * delta_z_l.
 //   hidden rows: row i of row tile p is input feature 32p + i of layer l (natural order = the A-operand row, so the C
 //                fragment of the backward GEMM lines up lane for lane with the sigma' the forward sweep stashed);
@@ -280,30 +283,94 @@ __device__ __forceinline__ void pack32_t_body(const PackArgs& a, unsigned block)
     if (l < 0) return;
     const LayerDesc Ld = a.L.layer[l];
     int idx = (int)(F - base);
-    const int part = idx % NP; idx /= NP;
-    const int u = idx & 1; idx >>= 1;
-    const int S = idx % NKS;
-    const int p = idx / NKS;
     const int i = lane & 31, hh = lane >> 5;
     const float* rs = reinterpret_cast<const float*>(a.packed + a.L.rowscale_off_bytes);
     const float mult = (l == a.L.skip_l) ? 0.70710678118654752440f : 1.0f;
     const int n_in = a.in_dim[l];
-    int col = -1;   // column of W_l this row stands for
-    if (!pe) {
-        const int f = 32 * p + i;
-        if (f < Ld.in_prev) col = f;
-    } else {
+    // row i of row tile p -> column `col` of W_l
+    auto col_of = [&](int p) -> int {
+        if (!pe) {
+            const int f = 32 * p + i;
+            return (f < Ld.in_prev) ? f : -1;
+        }
         const int hc = (i >> 2) & 1, r = (i & 3) + 4 * (i >> 3);
         const int pcol = pe_col_of(16 * hc + 8 * p + 4 * (r >> 3) + ((r & 7) >> 1), r & 1, M, d0);
-        if (pcol >= 0) col = (l == 0) ? pcol : Ld.in_prev + pcol;
-    }
-    float w[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
+        return (pcol >= 0) ? ((l == 0) ? pcol : Ld.in_prev + pcol) : -1;
+    };
+    auto weight = [&](int col, int S, int u, int e) -> float {
         const int o = 32 * S + (e & 3) + 8 * (2 * u + (e >> 2)) + 4 * hh;
-        w[e] = (o < Ld.out_dim && col >= 0 && col < n_in) ? rs[l * H + o] * a.v[l][(size_t)o * n_in + col] * mult : 0.f;
+        return (o < Ld.out_dim && col >= 0 && col < n_in) ? rs[l * H + o] * a.v[l][(size_t)o * n_in + col] * mult : 0.f;
+    };
+    char* dst = a.packed + a.L.r32_t_frag_off_bytes + F * FRAG_BYTES + lane * 16;
+    if (!r32_t_mixed(a.L)) {
+        const int part = idx % NP; idx /= NP;
+        const int u = idx & 1; idx >>= 1;
+        const int S = idx % NKS;
+        const int p = idx / NKS;
+        const int col = col_of(p);
+        float w[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) w[e] = weight(col, S, u, e);
+        store_frag(a, dst, w, part);
+        return;
     }
-    store_frag(a, a.packed + a.L.r32_t_frag_off_bytes + F * FRAG_BYTES + lane * 16, w, part);
+    // ---- mixed layout (split-fp16, d_hidden = 256): one 8 KiB block per (row tile p, K64-step Sg):
+    //   @0..3 KiB  hi16 fragments (S = 2Sg, u = 0), (2Sg, 1), (2Sg + 1, 0), (2Sg + 1, 1)
+    //   @4 KiB     W_hi6 registers q0..q3 (16 B / lane)        @5 KiB    W_lo6 q0..q3
+    //   @6 KiB     W_hi6 q4..q5 (8 B / lane)                   @6.5 KiB  W_lo6 q4..q5
+    //   @7 KiB     8 B / lane: E8M0 scales of this lane's blocks of steps Sg .. Sg+3, byte 2 j + (hi6 | lo6) for step Sg + j
+    // The cross terms W_hi x_lo + W_lo x_hi of the reverse sweep run as MX-scaled fp6 (e2m3) MFMAs of K = 64
+    // (v_mfma_scale_f32_32x32x64_f8f6f4, 4x the f16 rate; DESIGN.md par. 6c): lane (hh, i) of an fp6 block holds the 32 k-slots
+    // e = 16 pi + 8 u + e' <-> (S = 2Sg + pi, u, hh, e') of row i - the order in which a sweep lane holds its two row tiles' outputs -
+    // as six registers of e2m3.  hi6 quantises the f16 hi parts, lo6 the lo parts (x 2^11 in f16, undone in the scale byte); both
+    // through v_cvt_scalef32_pk32_fp6_f16, the instruction the sweep itself uses for its B operands (probed: natural element order,
+    // x / scale, RNE, saturating; profiles/r04_probe_fp6.txt).
+    const int f = idx & 7; idx >>= 3;
+    const int NSG = NKS / 2;
+    const int Sg = idx % NSG;
+    const int p = idx / NSG;
+    const int col = col_of(p);
+    if (f < 4) {
+        float w[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) w[e] = weight(col, 2 * Sg + (f >> 1), f & 1, e);
+        store_frag(a, dst, w, 0);
+        return;
+    }
+    // the lane's fp6 block of K64-step sg: its six registers and its E8M0 byte
+    auto block6 = [&](int sg, int part6, u32x6& q) -> uint32_t {
+        f16x32 v;
+        float m = 0.f;
+#pragma unroll
+        for (int e = 0; e < 32; ++e) {
+            const float w = weight(col, 2 * sg + (e >> 4), (e >> 3) & 1, e & 7);
+            const _Float16 h16 = (_Float16)w;
+            const _Float16 x = (part6 == 0) ? h16 : (_Float16)((w - (float)h16) * 2048.0f);
+            v[e] = x;
+            m = fmaxf(m, fabsf((float)x));
+        }
+        const uint32_t sb = mx6_scale_bits(m);
+        q = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(v, __builtin_bit_cast(float, sb));
+        return (sb >> 23) - (part6 ? 11u : 0u);
+    };
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    char* blk = a.packed + a.L.r32_t_frag_off_bytes + (F - f) * FRAG_BYTES;
+    u32x6 q;
+    if (f == 4 || f == 5) {
+        block6(Sg, f - 4, q);
+        *reinterpret_cast<u32x4*>(dst) = u32x4{q[0], q[1], q[2], q[3]};
+    } else if (f == 6) {
+        block6(Sg, 0, q);
+        *reinterpret_cast<u32x2*>(blk + 6 * FRAG_BYTES + lane * 8) = u32x2{q[4], q[5]};
+        block6(Sg, 1, q);
+        *reinterpret_cast<u32x2*>(blk + 6 * FRAG_BYTES + 512 + lane * 8) = u32x2{q[4], q[5]};
+    } else {
+        uint32_t sc[2] = {0u, 0u};
+        for (int j = 0; j < 4 && Sg + j < NSG; ++j)
+            for (int part6 = 0; part6 < 2; ++part6) sc[j >> 1] |= (block6(Sg + j, part6, q) & 255u) << (8 * (2 * (j & 1) + part6));
+        *reinterpret_cast<u32x2*>(blk + 7 * FRAG_BYTES + lane * 8) = u32x2{sc[0], sc[1]};
+    }
 }
 
 // fp32 copy of the last layer's real row (times its weight-norm scale): the seed of the reverse sweep

@@ -28,7 +28,7 @@ import sys
 RE_RANGE = re.compile(r"\bv\[(\d+):(\d+)\]")
 RE_SINGLE = re.compile(r"\bv(\d+)\b")
 RE_VMCNT = re.compile(r"s_waitcnt\b.*vmcnt\((\d+)\)")
-RE_LOAD = re.compile(r"^\s*global_load_dwordx4\s+v\[(\d+):(\d+)\]")
+RE_LOAD = re.compile(r"^\s*global_load_dwordx[234]\s+v\[(\d+):(\d+)\]")
 RE_NOP = re.compile(r"^\s*s_nop\s+(\d+)")
 WAR_WINDOW = 2        # MFMAs this many instructions (or fewer) before an asm load are checked
 WAR_WAIT_STATES = 5   # required between such an MFMA and the load that overwrites one of its source registers
