@@ -436,6 +436,21 @@ def main():
     ro, rd, near, far, ds = [t[sl].contiguous().to(dev) for t in g]
     tr, te = tr[sl].contiguous().to(dev), te[sl].contiguous().to(dev)
 
+    if a.mode == "train" and a.path != "native":
+        # the reference runner's own optimizer step on the drop-in classes (one GPU: EMAP itself is single-GPU)
+        if world != 1:
+            raise SystemExit("bench.py --path dropin runs on one GPU (the reference's loop has no data parallelism)")
+        res = train_dropin_key(dev, a.precision, rays, steps=a.steps, warmup=a.warmup + a.settle_steps // 10, fused_adam=(a.path == "dropin-fused"))
+        line = {"metric": res["metric"], "value": res["value"], "unit": "ray-samples/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
+                "ms_per_step": res["ms_per_step"], "ms_per_step_median": res["ms_per_step_median"], "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": MODE_DTYPE[a.precision], "data": "synthetic",
+                "config": {"workload": f"{rays} rays x {res['samples_per_ray']} samples, UDF MLP d=8 w=256 multires=10, optimizer step as "
+                                       f"src/runner/runner_udf.py:63-168 takes it, on the drop-in classes ({a.path})",
+                           "mode": "train", "path": a.path, "precision": a.precision, "host_syncs_per_step": res["host_syncs_per_step"]},
+                "whole_step_frac_of_mfma_peak": res["value"] * A_TRAIN / 1e12 / MFMA_PEAK_TFLOPS, "loss_after_run": res["loss_after_run"]}
+        print(json.dumps(line), flush=True)
+        return
+
     trainer = None
     if a.mode == "train":
         # The training loop of runner_udf.py:79-168 on a synthetic wire-frame scene (no datasets travel): every step draws its
@@ -677,8 +692,10 @@ def main():
                 line["train"] = {"error": repr(e)}
             try:    # the reference runner's own step through the drop-in classes
                 line["train_dropin"] = train_dropin_key(dev, a.precision, rays)
+                line["train_dropin_fused_adam"] = train_dropin_key(dev, a.precision, rays, fused_adam=True)
                 if isinstance(line.get("train"), dict) and line["train"].get("ms_per_step"):
-                    line["train_dropin"]["vs_native_trainer"] = line["train_dropin"]["ms_per_step"] / line["train"]["ms_per_step"]
+                    for k in ("train_dropin", "train_dropin_fused_adam"):
+                        line[k]["vs_native_trainer"] = line[k]["ms_per_step"] / line["train"]["ms_per_step"]
             except Exception as e:
                 line["train_dropin"] = {"error": repr(e)}
             try:

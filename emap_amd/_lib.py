@@ -110,6 +110,7 @@ SYMBOLS = {
     "emap_train_stats": (C.c_int, [_P, _P, _P, C.c_int, C.c_float, _P, _P, _P]),
     "emap_train_loss": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, _P, _P]),
     "emap_adam_step": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
+    "emap_adam_step_masked": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P, _P]),
     "emap_profile_enable": (C.c_int, [C.c_int]),
     "emap_profile_read": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "emap_profile_read_kernel": (C.c_int, [C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]),

@@ -39,17 +39,28 @@ __global__ void train_loss_kernel(const float* stats, float w_over_n, float igr,
 
 // torch.optim.Adam (amsgrad=False, weight_decay=0, maximize=False), the arithmetic of torch's fused kernel:
 //   m = lerp(m, g, 1-b1);  v = b2 v + (1-b2) g^2;  p -= (lr / (1-b1^t)) * m / (sqrt(v) / sqrt(1-b2^t) + eps)
+// tail_mask / tail_step (may be null: every element trainable, one global step count): per element of the tail [n_geo, n) - the
+// scalars variance / beta / gamma - whether it is trainable (requires_grad) and its OWN step count: torch.optim.Adam skips a parameter
+// without gradient and starts its `step` state when the parameter first gets one (runner_udf.py:144-154 un-freezes variance / beta late)
 __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, float* step, long long n, long long n_geo,
-                                                   float lr_geo, float lr, float b1, float b2, float eps) {
+                                                   float lr_geo, float lr, float b1, float b2, float eps, const float* tail_mask,
+                                                   float* tail_step) {
     const float t = *step + 1.0f;
     const float bc1 = 1.0f - powf(b1, t), bc2s = sqrtf(1.0f - powf(b2, t));
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        float c1 = bc1, c2s = bc2s;
+        if (i >= n_geo && tail_mask) {
+            if (tail_mask[i - n_geo] == 0.0f) continue;                  // frozen: no update, no state change
+            const float tt = tail_step[i - n_geo] + 1.0f;
+            tail_step[i - n_geo] = tt;
+            c1 = 1.0f - powf(b1, tt); c2s = sqrtf(1.0f - powf(b2, tt));
+        }
         const float gi = g[i];
         const float mi = m[i] + (gi - m[i]) * (1.0f - b1);
         const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
         m[i] = mi; v[i] = vi;
-        const float step_size = ((i < n_geo) ? lr_geo : lr) / bc1;
-        p[i] -= step_size * mi / (sqrtf(vi) / bc2s + eps);
+        const float step_size = ((i < n_geo) ? lr_geo : lr) / c1;
+        p[i] -= step_size * mi / (sqrtf(vi) / c2s + eps);
     }
 }
 __global__ void adam_bump_kernel(float* step) { *step += 1.0f; }
@@ -66,11 +77,14 @@ int launch_train_loss(const float* stats, float w_over_n, float igr, float igr_n
     return check_launch("train_loss");
 }
 int launch_adam(float* p, const float* g, float* m, float* v, float* step, int64_t n, int64_t n_geo, float lr_geo, float lr, float b1,
-                float b2, float eps, hipStream_t st) {
-    if (!p || !g || !m || !v || !step || n < 0 || n_geo < 0 || n_geo > n) { set_error("adam_step: bad arguments"); return EMAP_E_INVALID; }
+                float b2, float eps, const float* tail_mask, float* tail_step, hipStream_t st) {
+    if (!p || !g || !m || !v || !step || n < 0 || n_geo < 0 || n_geo > n || ((tail_mask == nullptr) != (tail_step == nullptr))) {
+        set_error("adam_step: bad arguments");
+        return EMAP_E_INVALID;
+    }
     if (n == 0) return EMAP_OK;
     const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-    hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, st, p, g, m, v, step, (long long)n, (long long)n_geo, lr_geo, lr, b1, b2, eps);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, st, p, g, m, v, step, (long long)n, (long long)n_geo, lr_geo, lr, b1, b2, eps, tail_mask, tail_step);
     hipLaunchKernelGGL(adam_bump_kernel, dim3(1), dim3(1), 0, st, step);
     return check_launch("adam_step");
 }

@@ -130,6 +130,12 @@ class Trainer:
             self._m = torch.zeros(self.flat.numel, device=dev)
             self._v = torch.zeros(self.flat.numel, device=dev)
             self._adam_t = torch.zeros(1, device=dev)          # step counter on the device: the update is graph-capturable
+            # the scalars' trainable mask and their own step counts live on the device too (emap_adam_step_masked): no host index tensors
+            # in the step, nothing a captured graph could bake in.  The mask is refreshed from requires_grad at every step() / replay().
+            self._tail_mask = torch.ones(self.flat.numel - g1, device=dev)
+            self._tail_step = torch.zeros(self.flat.numel - g1, device=dev)
+            self._tail_flags = None
+            self._mask_pinned = torch.ones(self.flat.numel - g1).pin_memory() if dev.type == "cuda" else None
             self._stats = torch.zeros(5, device=dev)
             self.optimizer = _AdamGroups(self, lr_geo, lr)
         else:
@@ -156,14 +162,41 @@ class Trainer:
         self.r.backward_into(call, v, d_edge, None, self._igr, self._igr_ns if self.igr_ns_weight != 0.0 else None,
                              flat=flat_grad, scalars=scalars_glob)
 
+    def _scalar_flags(self):
+        for p in self.geo:
+            if not p.requires_grad:
+                raise NotImplementedError("Trainer: a UDF network parameter with requires_grad=False is not supported")
+        return tuple(bool(p.requires_grad) for p in self.scalars)
+
+    def refresh_trainable_mask(self, capturing: bool = False):
+        """Mirror `requires_grad` of variance / beta / gamma (runner_udf.py:141-154 flips them during training) into the device mask
+        of the fused Adam.  Eager: called by every step.  Under a captured graph the mask BUFFER is what the graph reads, so a
+        refresh between replays takes effect without re-capturing."""
+        flags = self._scalar_flags()
+        if flags == self._tail_flags:
+            return False
+        if capturing:
+            raise RuntimeError("Trainer: requires_grad of variance / beta / gamma changed inside a graph capture")
+        vals = []
+        for p, f in zip(self.scalars, flags):
+            vals += [1.0 if f else 0.0] * p.numel()
+        if self._mask_pinned is not None:
+            self._mask_pinned.copy_(torch.tensor(vals))
+            self._tail_mask.copy_(self._mask_pinned, non_blocking=True)
+        else:
+            self._tail_mask.copy_(torch.tensor(vals))
+        self._tail_flags = flags
+        return True
+
     def _native_adam(self):
         from . import _lib
         g0, g1 = self.optimizer.param_groups
         dev = self.flat.data.device
         with torch.cuda.device(dev):
-            _lib.check(_lib.lib().emap_adam_step(_lib.ptr(self.flat.data), _lib.ptr(self.flat.grad), _lib.ptr(self._m), _lib.ptr(self._v),
-                                                 _lib.ptr(self._adam_t), self.flat.numel, self._n_geo, float(g0["lr"]), float(g1["lr"]),
-                                                 float(g0["betas"][0]), float(g0["betas"][1]), float(g0["eps"]), _lib.stream_ptr(dev)),
+            _lib.check(_lib.lib().emap_adam_step_masked(_lib.ptr(self.flat.data), _lib.ptr(self.flat.grad), _lib.ptr(self._m), _lib.ptr(self._v),
+                                                        _lib.ptr(self._adam_t), self.flat.numel, self._n_geo, float(g0["lr"]), float(g1["lr"]),
+                                                        float(g0["betas"][0]), float(g0["betas"][1]), float(g0["eps"]),
+                                                        _lib.ptr(self._tail_mask), _lib.ptr(self._tail_step), _lib.stream_ptr(dev)),
                        "adam_step")
 
     # The native step is written as four device phases separated by the (at most three) collectives, so that it can run eagerly, be
@@ -213,14 +246,7 @@ class Trainer:
         stats = self._stats
         if S["world"] > 1 and self.eikonal_sync == "local":
             stats = self.flat.grad[self.flat.numel:self.flat.numel + 5]
-        frozen = self._frozen_scalars()
-        if frozen:
-            keep = self.flat.data[frozen].clone()
-        self.optimizer.step()
-        if frozen:       # torch.optim.Adam skips a parameter without gradient (runner_udf.py:150-154: variance frozen until set_trainable)
-            self.flat.data[frozen] = keep
-            self._m[frozen] = 0.0
-            self._v[frozen] = 0.0
+        self.optimizer.step()      # frozen scalars are skipped inside the kernel (device mask, refresh_trainable_mask)
         self.r.udf_network.invalidate_packed()   # the flat update does not bump the per-parameter version counters
         out = torch.empty(2, device=dev)         # a fresh tensor per step: callers keep what step() returned
         with torch.cuda.device(dev):
@@ -228,19 +254,6 @@ class Trainer:
                                          _lib.stream_ptr(dev)), "train_loss")
         self.last_stats = out
         return out
-
-    def _frozen_scalars(self):
-        """Flat indices of variance / beta / gamma entries whose parameter has requires_grad=False; a frozen NETWORK tensor raises
-        (no EMAP configuration freezes one, and the fused update has no per-tensor skip)."""
-        for p in self.geo:
-            if not p.requires_grad:
-                raise NotImplementedError("Trainer: a UDF network parameter with requires_grad=False is not supported")
-        idx = []
-        for p in self.scalars:
-            if not p.requires_grad:
-                o = self.flat.offsets[id(p)]
-                idx += list(range(o, o + p.numel()))
-        return idx
 
     def _collectives(self):
         """The collectives of one step, in order, as (after_phase, callable): exact = [global eikonal mask sums + MSE sum (20 B),
@@ -274,6 +287,7 @@ class Trainer:
         """One optimizer step on this rank's rays.  Returns the device tensor [loss, edge_loss] of the GLOBAL batch (no host
         synchronisation happens here)."""
         if self.native_tail:
+            self.refresh_trainable_mask(capturing=torch.cuda.is_current_stream_capturing())
             return self._step_native(rays, true_edge, n_rays_global)
         world = _world(self.group)
         call, v, edge, scalars = self._forward(rays)
@@ -297,7 +311,18 @@ class Trainer:
             dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
             if self.eikonal_sync == "local":
                 stats = g[self.flat.numel:self.flat.numel + 5].clone()
+        # torch.optim.Adam on the two flat parameters cannot skip single elements: a frozen scalar (requires_grad = False,
+        # runner_udf.py:144-154) is put back and its moments cleared (CPU tests only; the native path masks inside the kernel)
+        frozen = [i for p in self.scalars if not p.requires_grad
+                  for i in range(self.flat.offsets[id(p)] - self.flat.offsets[id(self.scalars[0])], self.flat.offsets[id(p)] - self.flat.offsets[id(self.scalars[0])] + p.numel())]
+        keep = self.p_sc.data[frozen].clone() if frozen else None
         self.optimizer.step()
+        if frozen:
+            self.p_sc.data[frozen] = keep
+            st = self.optimizer.state.get(self.p_sc, {})
+            for k in ("exp_avg", "exp_avg_sq"):
+                if k in st:
+                    st[k][frozen] = 0.0
         self.r.udf_network.invalidate_packed()   # the flat update does not bump the per-parameter version counters
         edge_loss = stats[4] / n_glob * self.edge_weight
         loss = edge_loss + self.igr_weight * stats[2] / (stats[0] + 1e-5) + self.igr_ns_weight * stats[3] / (stats[1] + 1e-5)
@@ -316,7 +341,10 @@ class Trainer:
         launched between the replays - nothing about the transport is assumed (works with RCCL and with gloo, whose collectives
         are host code and cannot be captured); `segmented=False` puts the collectives inside one graph (RCCL only)."""
         if not self.native_tail:
-            segmented = False if segmented is None else segmented
+            if segmented:
+                raise ValueError("Trainer.capture(segmented=True) needs the native tail (native_tail=True): the per-phase graphs are the "
+                                 "native step's four device phases")
+            segmented = False
         world = _world(self.group)
         if segmented is None:
             segmented = world > 1
@@ -357,6 +385,8 @@ class Trainer:
         keep = self.r.live_buffers()
 
         def replay(rays: Optional[Dict] = None, true_edge: Optional[torch.Tensor] = None):
+            if self.native_tail:
+                self.refresh_trainable_mask()     # a set_trainable() between replays reaches the captured Adam through its mask buffer
             if rays is not None:
                 for k, v in rays.items():
                     if isinstance(v, torch.Tensor):
@@ -375,6 +405,91 @@ class Trainer:
         replay.segmented = bool(segmented)
         replay._keep = keep
         return replay
+
+
+class FusedAdam(torch.optim.Optimizer):
+    """``torch.optim.Adam`` for the drop-in's training loop (runner_base.py:106-117) as ONE kernel launch per step.
+
+    Same constructor shape as ``torch.optim.Adam([{"params": geo, "lr": lr_geo}, {"params": rest}, ...], lr=lr)``: the parameters of
+    the first non-empty group become the "geo" range, all later ones the tail.  On the first ``step()`` every parameter is re-homed as a
+    view of one flat fp32 buffer (their values, ``requires_grad`` flags and identities are kept - the modules never notice); a
+    step then gathers the gradients into one flat buffer (one ``torch.cat``) and calls ``emap_adam_step_masked``: a parameter whose
+    ``.grad`` is None (frozen: ``variance`` before ``set_trainable()``) is skipped exactly as torch's Adam skips it and its step
+    count starts when it first gets a gradient.  ``param_groups[i]["lr"]`` is read at every step, so the runner's schedulers work
+    unchanged.  Replaces 32 tensors x ~6 element-wise launches of the stock optimizer."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        groups = [g for g in self.param_groups if len(g["params"])]
+        if not groups:
+            raise ValueError("FusedAdam: no parameters")
+        self._geo_group = groups[0]
+        self._tail_groups = groups[1:]
+        if len({g["lr"] for g in self._tail_groups}) > 1:
+            raise ValueError("FusedAdam: the groups behind the first one must share one learning rate (the runner's do)")
+        self._flat = None
+
+    def _build(self):
+        geo = list(self._geo_group["params"])
+        tail = [p for g in self._tail_groups for p in g["params"]]
+        grads = [p.grad for p in geo + tail]    # FlatParams points .grad at its own flat buffer; this optimizer takes the gradients autograd
+        self._flat = FlatParams(geo + tail)     # (or the caller) put there, so they are put back
+        for p, g_ in zip(geo + tail, grads):
+            p.grad = g_
+        dev = self._flat.data.device
+        self._n_geo = sum(p.numel() for p in geo)
+        self._geo, self._tail = geo, tail
+        n = self._flat.numel
+        self._m, self._v = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+        self._t = torch.zeros(1, device=dev)
+        self._tail_mask = torch.ones(max(n - self._n_geo, 1), device=dev)
+        self._tail_step = torch.zeros(max(n - self._n_geo, 1), device=dev)
+        self._flags = None
+        self._zeros = {}
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        from . import _lib
+        loss = closure() if closure is not None else None
+        if self._flat is None:
+            self._build()
+        dev = self._flat.data.device
+        parts = []
+        for p in self._geo:
+            if p.grad is None:
+                raise NotImplementedError("FusedAdam: a parameter of the first group without gradient")
+            parts.append(p.grad.reshape(-1))
+        flags = []
+        for p in self._tail:
+            has = p.grad is not None
+            flags += [1.0 if has else 0.0] * p.numel()
+            if has:
+                parts.append(p.grad.reshape(-1))
+            else:
+                z = self._zeros.get(p.numel())
+                if z is None:
+                    z = self._zeros[p.numel()] = torch.zeros(p.numel(), device=dev)
+                parts.append(z)
+        if flags != self._flags:                # rare: a set_trainable() of the runner
+            self._tail_mask[:len(flags)].copy_(torch.tensor(flags))
+            self._flags = flags
+        grad = torch.cat(parts)
+        lr_tail = self._tail_groups[0]["lr"] if self._tail_groups else self._geo_group["lr"]
+        b1, b2 = self._geo_group["betas"]
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().emap_adam_step_masked(_lib.ptr(self._flat.data), _lib.ptr(grad), _lib.ptr(self._m), _lib.ptr(self._v),
+                                                        _lib.ptr(self._t), self._flat.numel, self._n_geo, float(self._geo_group["lr"]),
+                                                        float(lr_tail), float(b1), float(b2), float(self._geo_group["eps"]),
+                                                        _lib.ptr(self._tail_mask), _lib.ptr(self._tail_step), _lib.stream_ptr(dev)),
+                       "adam_step")
+        # the in-place flat update is invisible to the per-tensor version counters UDFNetwork.packed() keys its fragment cache on
+        inc = getattr(torch.autograd.graph, "increment_version", None)
+        for p in self._geo:
+            if inc is not None:
+                inc(p)
+            else:
+                p.add_(0.0)
+        return loss
 
 
 # ---------------------------------------------------------------------------------------------

@@ -318,6 +318,13 @@ int emap_train_stats(const float* edge, const float* true_edge, const float* sca
 int emap_train_loss(const float* stats5, float w_over_n, float igr_weight, float igr_ns_weight, float* out2, void* stream);
 int emap_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* step_dev, int64_t n, int64_t n_geo,
                    float lr_geo, float lr, float beta1, float beta2, float eps, void* stream);
+/* emap_adam_step_masked : the same with per-element state for the tail [n_geo, n) (the scalars variance / beta / gamma, which the runner
+ *                    freezes and un-freezes: runner_udf.py:141-154): tail_mask[j] = 1 trainable / 0 frozen (torch.optim.Adam skips a
+ *                    parameter without gradient: no update, no state change), tail_step[j] = that element's own step count
+ *                    (bias correction restarts when a parameter is un-frozen, as torch's per-parameter `step`).  Both device
+ *                    arrays of n - n_geo floats: no host index tensors, graph-capturable (ABI 6). */
+int emap_adam_step_masked(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* step_dev, int64_t n, int64_t n_geo,
+                          float lr_geo, float lr, float beta1, float beta2, float eps, const float* tail_mask, float* tail_step, void* stream);
 
 /* ---- dense-grid extraction (SURVEY par. 8 f2) ----------------------------------------------------
  * emap_null_direction : `_, _, vh = torch.linalg.svd(grad_ld); F.normalize(vh[:, -1, :])` of get_udf_normals_grid /

@@ -191,6 +191,10 @@ def g5_render():
         "c64_64_4": ("d8w256L10", 64, 64, 4),
         "c32_32_4_small": ("d4w128L10", 32, 32, 4),
         "c64_64_4_L6": ("d8w256L6", 64, 64, 4),
+        # n_importance = 0: render() skips importance_sample (udf_renderer_blending.py:740) - SURVEY par. 8d's second reading of
+        # config C1 ("S_c = 64, S_f = 0"), on the C1 network and on the d8 w256 one
+        "c64_0": ("d8w256L10", 64, 0, 4),
+        "c64_0_small": ("d4w128L10", 64, 0, 4),
     }
     N = 32
     for cname, (netname, ns, ni, steps) in cases.items():
@@ -267,6 +271,64 @@ def g6_training():
         d["grad.beta"] = bet.beta.grad if bet.beta.grad is not None else torch.zeros(1)
         d["grad.gamma"] = bet.gamma.grad if bet.gamma.grad is not None else torch.zeros(1)
         save(f"g6_training_{ci}", **d)
+
+
+def g12_training_steps():
+    """A short TRAINING RUN recorded from the reference's own classes: 48 optimizer steps of the loop of runner_udf.py:63-168 -
+    render() under autograd, EdgeLoss, the loss assembly, loss.backward(), torch.optim.Adam with the runner's parameter groups
+    (runner_base.py:106-117) and its schedules (runner_base.py:128-180: warm-up + cosine learning rates per group, cos_anneal_ratio,
+    flip_saturation) with the iteration axis compressed (warm_up_end 8, end_iter 48, anneal_end 16).  The runner module itself
+    cannot be imported here (pyhocon, cv2, tensorboard), so its loop body is restated around the reference's model classes; the
+    rays of step i come from this repo's seeded generator.  Pins row a15's optimizer tail to the reference (VERDICT r3 item 5 iv)."""
+    netname, ns, ni, steps_up, N, n_steps = "d4w128L10", 32, 32, 4, 64, 48
+    net, _ = build_net(netname)
+    r, dev, bet = make_renderer(net, ns, ni, steps_up)
+    lr, lr_geo, alpha, warm_up_end, end_iter, anneal_end, fix_geo_end = 5e-4, 1e-4, 0.05, 8, n_steps, 16, 0
+    edge_weight, igr_weight, igr_ns_weight = 1.0, 0.1, 0.0
+    opt = torch.optim.Adam([{"params": list(net.parameters()), "lr": lr_geo},
+                            {"params": list(dev.parameters()) + list(bet.parameters())},
+                            {"params": []}], lr=lr)
+    loss_fn = EdgeLoss("mse")
+    losses, edge_losses, ges, variances, betas, lrs = [], [], [], [], [], []
+    for it in range(n_steps):
+        # update_learning_rate(start_g_id=1) + update_learning_rate_geo()  (runner_udf.py:64-68, same_lr = False)
+        if it < warm_up_end:
+            f = it / warm_up_end
+        else:
+            f = (np.cos(np.pi * (it - warm_up_end) / (end_iter - warm_up_end)) + 1.0) * 0.5 * (1 - alpha) + alpha
+        for g in opt.param_groups[1:]:
+            g["lr"] = lr * f
+        if it < fix_geo_end:
+            fg = 0.0
+        elif it < warm_up_end * 2:
+            fg = it / (warm_up_end * 2)
+        elif it < end_iter * 0.5:
+            fg = 1.0
+        else:
+            fg = (np.cos(np.pi * (it - end_iter * 0.5) / (end_iter - end_iter * 0.5)) + 1.0) * 0.5 * (1 - alpha) + alpha
+        for g in opt.param_groups[:1]:
+            g["lr"] = lr_geo * fg
+        car = float(np.min([1.0, it / anneal_end]))
+        fs = 0.0                                        # get_flip_saturation(): 0 before iteration 10000
+        rays_o, rays_d, near, far, depth_scale = synthetic.make_rays(N, seed=1000 + it)
+        true_edge = synthetic.make_true_edge(N, seed=2000 + it)
+        out = r.render(rays_o, rays_d, near, far, depth_scale, cos_anneal_ratio=car, perturb_overwrite=0, flip_saturation=fs)
+        edge_loss = loss_fn(out["edge"], true_edge) * edge_weight
+        loss = edge_loss + out["gradient_error_near_surface"] * igr_ns_weight + out["gradient_error"] * igr_weight
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss)); edge_losses.append(float(edge_loss)); ges.append(float(out["gradient_error"]))
+        variances.append(float(dev.variance)); betas.append(float(bet.beta)); lrs.append([lr_geo * fg, lr * f])
+    d = {"netname": np.array(netname), "cfg": np.array([ns, ni, steps_up]), "n_rays": np.array(N), "n_steps": np.array(n_steps),
+         "ray_seed0": np.array(1000), "edge_seed0": np.array(2000), "weights3": np.array([edge_weight, igr_weight, igr_ns_weight]),
+         "schedule": np.array([lr, lr_geo, alpha, warm_up_end, end_iter, anneal_end, fix_geo_end]),
+         "loss": np.array(losses), "edge_loss": np.array(edge_losses), "gradient_error": np.array(ges),
+         "variance": np.array(variances), "beta": np.array(betas), "lrs": np.array(lrs)}
+    for k, p in net.named_parameters():
+        d["final." + k] = p.detach()
+    d["final.gamma"] = bet.gamma.detach()
+    save("g12_training_steps", **d)
 
 
 def g7_perturb():
@@ -421,6 +483,6 @@ def g11_rays():
 if __name__ == "__main__":
     only = sys.argv[1:]
     for fn in (g1_pe, g2_mlp, g3_sample_pdf, g4_upsample_step, g5_render, g6_training, g7_perturb, g8_scalars, g9_seeded_init,
-               g10_extraction, g11_rays):
+               g10_extraction, g11_rays, g12_training_steps):
         if not only or fn.__name__ in only:
             fn()
