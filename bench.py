@@ -74,6 +74,10 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N > 1: nccl (= RCCL, one rank per GPU) or gloo (debug: the ranks share the visible "
                          "GPUs round-robin and reduce through the host - runs every line of the N > 1 path on a one-GPU box)")
+    ap.add_argument("--dry-run-nccl", action="store_true",
+                    help="self-check of the RCCL branch: with >= 2 visible GPUs, run 2 ranks x 3 training steps over nccl (eager and from "
+                         "per-phase graphs) and print one JSON line with the outcome; with one GPU it reports 'skipped'.  Meant to be the "
+                         "first command on a multi-GPU lease.")
     ap.add_argument("--no-train-key", action="store_true", help="render mode, one GPU: skip the short training-step measurement")
     ap.add_argument("--no-other-modes", action="store_true", help="skip the short runs of the other precision modes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -393,10 +397,35 @@ def cpu_baseline(state, kw, n_rays, mode):
                       f"{best['threads']} threads (best of {sorted(c['threads'] for c in res)} threads); oracle/emap_oracle.py on torch CPU fp32"}
 
 
+def dry_run_nccl():
+    """`python bench.py --dry-run-nccl`: constructs the nccl (= RCCL) process group on 2 GPUs and takes three training steps eagerly and
+    three from per-phase graphs, so that the first multi-GPU lease is not spent debugging the launch path."""
+    n = torch.cuda.device_count()
+    if n < 2:
+        print(json.dumps({"dry_run_nccl": "skipped", "reason": f"{n} GPU(s) visible; the RCCL branch needs 2"}), flush=True)
+        return 0
+    outs = {}
+    for graph in ("off", "on"):
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "2", "--mode", "train", "--steps", "3", "--warmup", "1", "--settle-steps", "2",
+               "--graph", graph, "--no-cpu-baseline", "--no-parity"]
+        try:
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            ln = [x for x in p.stdout.splitlines() if x.startswith("{")]
+            outs[graph] = {"rc": p.returncode, "ms_per_step": (json.loads(ln[-1])["ms_per_step"] if ln else None),
+                           "stderr_tail": p.stderr[-400:] if p.returncode else ""}
+        except subprocess.TimeoutExpired:
+            outs[graph] = {"rc": None, "error": "timeout after 600 s"}
+    ok = all(o.get("rc") == 0 for o in outs.values())
+    print(json.dumps({"dry_run_nccl": "ok" if ok else "FAILED", "ranks": 2, "eager": outs["off"], "per_phase_graphs": outs["on"]}), flush=True)
+    return 0 if ok else 1
+
+
 def main():
     a = parse()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    if a.dry_run_nccl:
+        sys.exit(dry_run_nccl())
     launched = "WORLD_SIZE" in os.environ
     if a.gpus > 1 and not launched:
         if torch.cuda.device_count() < a.gpus and a.backend == "nccl":

@@ -82,20 +82,24 @@ class ParamLayout:
         return out
 
 
-_WS_MAX_ENTRIES = 8   # distinct launch shapes per cache (training batch, validation chunk, ...): far fewer in practice
+_WS_MAX_ENTRIES = 8            # distinct launch shapes per cache (training batch, validation chunk, ...): far fewer in practice
+_WS_BUDGET_BYTES = 24 << 30    # ... and their total size: the backward's preferred workspace is ~17 KiB per point (8.8 GB at 4096 x 128)
 
 
 def _workspace(cache: dict, key, nbytes: int, dev) -> torch.Tensor:
-    """Cached scratch buffer for one launch shape.  The cache keeps one buffer PER KEY and never frees or moves a buffer that is
-    still big enough: a captured hipGraph (UDFRendererBlending.capture, Trainer.capture) has the device pointers of the buffers of
-    ITS shape baked in, so a render of another shape in between (validation.render_image between replays of a training graph) must
-    not evict them.  Only when more than _WS_MAX_ENTRIES shapes have been seen is the least recently used entry dropped - callers
-    that capture graphs hold their own references as well."""
+    """Cached scratch buffer for one launch shape.  The cache keeps one buffer PER KEY and never moves one that is still big enough:
+    a captured hipGraph (UDFRendererBlending.capture, Trainer.capture) has the device pointers of the buffers of ITS shape baked in,
+    so a render of another shape in between (validation.render_image between replays of a training graph) must not evict them.
+    Entries are dropped least-recently-used first once the cache holds more than _WS_MAX_ENTRIES shapes OR more than
+    _WS_BUDGET_BYTES (a caller with a varying point count - UdfFn on ragged extraction batches - would otherwise pin one multi-GB
+    backward workspace per size).  Dropping an entry only drops the CACHE's reference: a captured graph holds its own
+    (``live_buffers``), so its buffers stay where they are.  ``UDFNetwork.backward_workspace_limit`` caps a single workspace."""
     key = (key, str(dev))
     ws = cache.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        if len(cache) >= _WS_MAX_ENTRIES and key not in cache:
+        cache.pop(key, None)
+        while cache and (len(cache) >= _WS_MAX_ENTRIES or sum(b.numel() for b in cache.values()) + nbytes > _WS_BUDGET_BYTES):
             cache.pop(next(iter(cache)))
     else:
         cache.pop(key)          # re-insert: dict order = recency

@@ -273,6 +273,7 @@ __device__ __forceinline__ float wave_sum_f(float v) {
 // 4 consecutive output rows per wave: they are the 4 accumulator registers of one lane of the MFMA output, i.e. ONE 16-byte
 // word of the partial blocks per (column, slice) - every load is a float4 and a wave reads 256-byte runs.
 constexpr int RED_WAVES = EMAP_REDUCE_WAVES;   // waves of a row group: each sums every RED_WAVES-th K-slice
+static_assert(RED_WAVES >= 2 && RED_WAVES <= 16, "EMAP_REDUCE_WAVES: the cross-wave sum needs 2..16 waves (part[RED_WAVES - 1] in LDS)");
 __global__ __launch_bounds__(RED_WAVES * 64) void wgrad_reduce_kernel(const ReduceArgs a) {
     // one workgroup per group of 4 rows: its 4 waves each sum every 4th K-slice (there are only ~500 groups: with one wave per group
     // the kernel was a latency chain on two waves per CU), wave 0 adds the four partial sums in a fixed order and finishes the rows

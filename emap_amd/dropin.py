@@ -19,17 +19,38 @@ _ALIASES = {"src.models.udf_model": "emap_amd.udf_model",
             "src.models.loss": "emap_amd.loss"}
 
 
-def dataset_method(sampler_cls=None):
+def _default_seed():
+    """Seed of the device pixel draw when the dataset carries no ``emap_seed``: torch's seed (so ``torch.manual_seed`` in main.py
+    still selects the ray stream) plus the rank of a data-parallel run (every rank its own stream)."""
+    import torch
+    seed = int(torch.initial_seed()) & 0x7fffffff
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            seed = (seed + 7919 * dist.get_rank()) & 0x7fffffff
+    except Exception:
+        pass
+    return seed
+
+
+def dataset_method(sampler_cls=None, original=None):
     """Replacement for ``Dataset.gen_random_rays_patches_at`` (src/dataset/dataset.py:222-307): the first call uploads the dataset's
     edge maps / intrinsics / poses once (``DeviceRaySampler``), every call is then ONE kernel launch and no host->device copy.
-    Returns the reference's dict (rays{rays_o, rays_v, edge}, pose, intrinsics, rays_ndc_uv, rays_norm_XYZ_cam, depth_scale)."""
+    Returns the reference's dict (rays{rays_o, rays_v, edge}, pose, intrinsics, rays_ndc_uv, rays_norm_XYZ_cam, depth_scale).
+    The pixel stream is a device Philox draw, NOT the reference's host RNG streams (torch.randint / random.choices): same
+    distribution, other pixels.  Seeded by ``dataset.emap_seed`` if set, else by ``torch.initial_seed()`` + rank.
+    A dataset on a non-CUDA device keeps the reference's own method (`original`)."""
     def gen_random_rays_patches_at(self, img_idx, batch_size, importance_sample=False):
+        import torch
+        if original is not None and torch.device(self.device).type != "cuda":
+            return original(self, img_idx, batch_size, importance_sample)
         s = getattr(self, "_emap_sampler", None)
         if s is None:
             cls = sampler_cls
             if cls is None:
                 from .ray_sampler import DeviceRaySampler as cls
-            s = cls(self.edges, self.intrinsics_all, self.pose_all, device=self.device, seed=getattr(self, "emap_seed", 0))
+            seed = getattr(self, "emap_seed", None)
+            s = cls(self.edges, self.intrinsics_all, self.pose_all, device=self.device, seed=_default_seed() if seed is None else seed)
             self._emap_sampler = s
         # the reference takes the importance branch only when the dataset has masks (:236-238)
         smp = s.gen_random_rays_patches_at(int(img_idx), batch_size, importance_sample=bool(importance_sample and self.masks is not None))
@@ -63,7 +84,11 @@ def _patch_dataset():
         ds = importlib.import_module("src.dataset.dataset")
     except Exception:
         return False
-    ds.Dataset.gen_random_rays_patches_at = dataset_method()
+    if getattr(ds.Dataset.gen_random_rays_patches_at, "_emap_patched", False):
+        return True
+    fn = dataset_method(original=ds.Dataset.gen_random_rays_patches_at)
+    fn._emap_patched = True
+    ds.Dataset.gen_random_rays_patches_at = fn
     return True
 
 
@@ -75,7 +100,8 @@ def _patch_runner():
     return True
 
 
-def install(force: bool = True):
+def install(force: bool = True, patch_dataset: bool = True):
+    """Alias ``src.models.*`` to this package; ``patch_dataset=False`` keeps the reference's host-side ray sampler (its RNG streams)."""
     for pkg in ("src", "src.models"):
         if pkg not in sys.modules:
             try:
@@ -89,7 +115,8 @@ def install(force: bool = True):
             mod = importlib.import_module(real)
             sys.modules[alias] = mod
             setattr(sys.modules["src.models"], alias.rsplit(".", 1)[1], mod)
-    _patch_dataset()
+    if patch_dataset:
+        _patch_dataset()
     _patch_runner()
     # extraction queries (SURVEY par. 8 f2): the reference module keeps its other functions; only the two query routines
     # are replaced, and only if the module can be imported at all (it needs nothing but torch)

@@ -71,17 +71,10 @@ def get_udf_normals_grid(func, func_grad, N, udf_threshold, is_linedirection=Fal
     if device.type != "cuda":
         raise RuntimeError("emap_amd.extraction runs on the GPU only (no CPU fallback)")
     net = _fast_net(func, func_grad)
-    overall_index = torch.arange(0, N ** 3, 1, device=device)
+    # the N^3 lattice on [-1, 1]^3, first coordinate slowest (the reference's point order and fp32 arithmetic, :36-54: index * 2/(N-1) - 1)
+    axis = torch.arange(N, device=device, dtype=torch.float32) * (2.0 / (N - 1)) + (-1)
     samples = torch.zeros(N ** 3, 12, device=device)
-    # grid coordinates exactly as the reference builds them (:38-54): index -> (i, j, k), * voxel_size + origin
-    samples[:, 2] = overall_index % N
-    samples[:, 1] = torch.div(overall_index, N, rounding_mode="floor") % N
-    samples[:, 0] = torch.div(torch.div(overall_index, N, rounding_mode="floor"), N, rounding_mode="floor") % N
-    voxel_origin = [-1, -1, -1]
-    voxel_size = 2.0 / (N - 1)
-    samples[:, 0] = (samples[:, 0] * voxel_size) + voxel_origin[2]
-    samples[:, 1] = (samples[:, 1] * voxel_size) + voxel_origin[1]
-    samples[:, 2] = (samples[:, 2] * voxel_size) + voxel_origin[0]
+    samples[:, :3] = torch.stack(torch.meshgrid(axis, axis, axis, indexing="ij"), dim=-1).reshape(-1, 3)
 
     with torch.no_grad():
         pts = samples[:, :3].contiguous()

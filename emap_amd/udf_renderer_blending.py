@@ -35,6 +35,53 @@ def sample_pdf(bins, weights, n_samples, det=False):
     return out
 
 
+class _ReducedOperand:
+    """Stand-in for a per-sample render() entry in the reduced-output launch mode (UDFRendererBlending._render_reduced_compat):
+    no per-sample tensor exists there.  Supports exactly the validation loop's expression (runner_udf.py:375-405)
+
+        (out["gradients_flip"] * out["weights"][:, :S, None]).sum(dim=1)      ->  the rendered normals (N, 3)
+
+    and ``is not None`` tests; everything else raises."""
+
+    def __init__(self, name, normals, S, stage="entry"):
+        self._name, self._normals, self._S, self._stage = name, normals, S, stage
+
+    def _no(self, what):
+        raise RuntimeError(f"emap_amd: render() ran in the reduced-output mode (inference_reduced): out['{self._name}'] has no per-sample values "
+                           f"({what}); only (gradients_flip * weights[:, :S, None]).sum(dim=1) is defined - render without inference_reduced")
+
+    def __getitem__(self, key):
+        ok = (self._name == "weights" and self._stage == "entry" and isinstance(key, tuple) and len(key) == 3 and key[0] == slice(None)
+              and isinstance(key[1], slice) and key[1].start in (None, 0) and key[1].step in (None, 1)
+              and (key[1].stop is None or key[1].stop >= self._S) and key[2] is None)
+        if not ok:
+            self._no(f"indexing with {key!r}")
+        return _ReducedOperand("weights", None, self._S, "sliced")
+
+    def __mul__(self, other):
+        if not (self._name == "gradients_flip" and self._stage == "entry" and isinstance(other, _ReducedOperand) and other._stage == "sliced"):
+            self._no("multiplication by anything but weights[:, :S, None]")
+        return _ReducedOperand("gradients_flip * weights", self._normals, self._S, "product")
+
+    def sum(self, dim=None, **kw):
+        if not (self._stage == "product" and dim == 1 and not kw):
+            self._no(f"sum(dim={dim!r})")
+        return self._normals
+
+    def __getattr__(self, item):          # .shape, .cpu(), .detach(), ...: there is nothing to look at
+        if item.startswith("__") and item.endswith("__"):
+            raise AttributeError(item)
+        self._no(f"attribute .{item}")
+
+    __rmul__ = __add__ = __radd__ = __sub__ = __truediv__ = __matmul__ = lambda self, other: self._no("arithmetic")
+
+    def __iter__(self):
+        self._no("iteration")
+
+    def __len__(self):
+        self._no("len()")
+
+
 class UDFRendererBlending:
     def __init__(self, nerf, udf_network, deviation_network, beta_network, n_samples, n_importance, n_outside,
                  up_sample_steps, perturb, sdf2alpha_type="numerical", upsampling_type="classical",
@@ -329,18 +376,18 @@ class UDFRendererBlending:
                                flip_saturation, t_rand):
         """render() for a caller that consumes per-ray results only - the validation loop, runner_udf.py:333-407: ``edge``, ``depth``
         and  sum_s gradients_flip[:, s] * weights[:, s]  - served by the reduced-output launch mode (no per-sample tensor leaves the
-        GPU kernels).  The two per-sample entries the loop multiplies are returned as broadcast stand-ins whose product sums to the
-        rendered normal: gradients_flip = normals (N,1,3), weights = 1/S (N,S) (zero-stride views, no memory).  Selected by
-        ``self.inference_reduced`` (emap_amd.dropin.validate_wrapper sets it around Runner_UDF.validate); only without autograd."""
+        GPU kernels).  The per-sample entries the loop touches are GUARDS, not tensors (``_ReducedOperand``): the one expression of
+        runner_udf.py:375-405, ``(gradients_flip * weights[:, :S, None]).sum(dim=1)``, evaluates to the rendered normals; any other use
+        of them raises instead of handing out made-up per-sample values.  Selected by ``self.inference_reduced``
+        (emap_amd.dropin.validate_wrapper sets it around Runner_UDF.validate); only without autograd."""
         o = self.render_reduced(rays_o, rays_d, near, far, depth_scale, cos_anneal_ratio, perturb_overwrite, background_rgb,
                                 flip_saturation, t_rand)
-        N, S = o["edge"].shape[0], self.samples_per_ray
-        dev = o["edge"].device
-        ones = torch.ones(1, 1, device=dev)
+        S = self.samples_per_ray
+        flip = _ReducedOperand("gradients_flip", o["normals"], S)
         return {"edge": o["edge"], "depth": o["depth"], "weight_sum": o["weight_sum"], "weight_sum_fg_bg": o["weight_sum"],
                 "normals": o["normals"], "gradient_error": o["gradient_error"], "sparse_error": o["sparse_error"],
-                "gradients_flip": o["normals"].view(N, 1, 3), "gradients": None,
-                "weights": (ones / S).expand(N, S), "inside_sphere": ones.expand(N, S), "reduced": True}
+                "gradients_flip": flip, "gradients": None,
+                "weights": _ReducedOperand("weights", None, S), "inside_sphere": _ReducedOperand("inside_sphere", None, S), "reduced": True}
 
     def capture(self, rays_o, rays_d, near, far, depth_scale, cos_anneal_ratio=None, background_rgb=None, flip_saturation=0,
                 t_rand=None, reduced=False):

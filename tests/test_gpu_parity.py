@@ -836,9 +836,15 @@ def test_validation_loop_consumption_through_the_reduced_mode():
         o = r.render(ro, rd, near, far, ds, cos_anneal_ratio=1.0, perturb_overwrite=0)
         red = consume(o)
         r.inference_reduced = False
-    assert o["reduced"] and o["inside_sphere"] is not None and o["weights"].shape == (512, S) and o["weights"].stride() == (0, 0)
+    assert o["reduced"] and o["inside_sphere"] is not None and o["gradients"] is None
     for a, b, tol in zip(red, full, (1e-6, 1e-6, 2e-6)):
         assert rel(a, b) <= tol
+    # the per-sample entries of the reduced mode are guards: any use but the loop's own product-sum raises
+    for bad in (lambda: o["weights"].shape, lambda: o["weights"].sum(), lambda: o["weights"][:, :4, None], lambda: o["gradients_flip"] * 2.0,
+                lambda: o["gradients_flip"].cpu(), lambda: o["inside_sphere"].float(), lambda: (o["gradients_flip"] * o["weights"][:, :S, None]).sum(dim=2),
+                lambda: o["gradients_flip"] * o["weights"]):
+        with pytest.raises(RuntimeError):
+            bad()
     # with trainable parameters and autograd on, the flag is ignored (the training path needs the per-sample tensors)
     r.inference_reduced = True
     o2 = r.render(ro[:32], rd[:32], near[:32], far[:32], ds[:32], cos_anneal_ratio=1.0, perturb_overwrite=0)
