@@ -66,7 +66,7 @@ def parse():
     ap.add_argument("--global-rays", type=int, default=0, help="rays of the GLOBAL batch, split over the ranks (strong scaling)")
     ap.add_argument("--precision", default=os.environ.get("EMAP_BENCH_PRECISION", "f16x3"), choices=list(MODE_DTYPE),
                     help="arithmetic of the MLP GEMMs for `value`; f16x3 is the mode that meets the 1e-4 parity gate")
-    ap.add_argument("--eikonal-sync", default="exact", choices=["exact", "local"], help="train mode, N > 1 (emap_amd/parallel.py)")
+    ap.add_argument("--eikonal-sync", default="exact_lagged", choices=["exact", "exact_lagged", "local"], help="train mode, N > 1 (emap_amd/parallel.py)")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="replay the step from a captured hipGraph (auto: render mode yes - falling back to eager launches if the "
                          "capture fails -, train mode no)")
@@ -651,7 +651,11 @@ def main():
                                                                f", {trainer.collectives_per_step} collective(s) per step "
                                                                f"(eikonal_sync={a.eikonal_sync}: "
                                                                + ("20 B statistics (SUM) + 8 B range maxima (MAX) + " if a.eikonal_sync == "exact" and world > 1 else "")
-                                                               + f"one flat {4 * (trainer.flat.numel + trainer.N_STATS)} B gradient all-reduce)"),
+                                                               + ("20 B statistics (SUM) + " if a.eikonal_sync == "exact_lagged" and world > 1 else "")
+                                                               + f"one flat {4 * trainer.flat.grad.numel()} B gradient all-reduce"
+                                                               + (" whose tail carries every rank's range maxima for the NEXT step" if a.eikonal_sync == "exact_lagged" and world > 1 else "")
+                                                               + ")"),
+                       "collectives_per_step": (trainer.collectives_per_step if a.mode == "train" else 0),
                        "ranks": world, "backend": (a.backend if world > 1 else None), "rccl_ranks": (world if (world > 1 and a.backend == "nccl") else 0),
                        "devices": ([(i if a.backend == "nccl" else i % torch.cuda.device_count()) for i in range(world)]),
                        "settle_steps": a.settle_steps},

@@ -93,12 +93,14 @@ class _AdamGroups:
 class Trainer:
     """Native data-parallel training step of the render hot path (see the module docstring)."""
 
-    N_STATS = 8
+    N_STATS = 8          # tail of the gradient bucket: [0, 5) the step statistics ("local"); then 2 range maxima per rank ("exact_lagged")
+    MAX_RANKS = 16
 
     def __init__(self, renderer, lr_geo: float = 1e-4, lr: float = 5e-4, edge_weight: float = 1.0, igr_weight: float = 0.1,
                  igr_ns_weight: float = 0.0, group=None, eikonal_sync: str = "exact", fused_adam: Optional[bool] = None,
                  native_tail: Optional[bool] = None):
-        assert eikonal_sync in ("exact", "local")
+        assert eikonal_sync in ("exact", "exact_lagged", "local")
+        assert _world(group) <= self.MAX_RANKS
         self.r = renderer
         self.group = group
         self.eikonal_sync = eikonal_sync
@@ -106,7 +108,7 @@ class Trainer:
         net = renderer.udf_network
         self.geo = list(net.parameters())
         self.scalars = [renderer.deviation_network.variance, renderer.beta_network.beta, renderer.beta_network.gamma]
-        self.flat = FlatParams(self.geo + self.scalars, extra=self.N_STATS)
+        self.flat = FlatParams(self.geo + self.scalars, extra=self.N_STATS + 2 * self.MAX_RANKS)
         renderer._lay = None                      # the layout caches tensor identities / pointers: rebuild on the flat views
         lay = renderer._layout()
         assert lay.numel == self.flat.numel and all(lay.offsets[id(p)] == self.flat.offsets[id(p)] for p in self.flat.params)
@@ -142,7 +144,11 @@ class Trainer:
             # capturable: the step counters live on the device, so a whole step can be captured in a hipGraph (capture())
             self.optimizer = torch.optim.Adam([{"params": [self.p_geo], "lr": lr_geo}, {"params": [self.p_sc]}], lr=lr,
                                               **({"fused": True, "capturable": True} if fused_adam else {}))
-        self.collectives_per_step = 0 if _world(group) == 1 else (3 if eikonal_sync == "exact" else 1)
+        # steady state: "exact" 3 (statistics SUM, range maxima MAX, gradients), "exact_lagged" 2 (the maxima ride in the gradient bucket
+        # and are used one step late; the very first step takes the exact path), "local" 1
+        self.collectives_per_step = 0 if _world(group) == 1 else {"exact": 3, "exact_lagged": 2, "local": 1}[eikonal_sync]
+        self._lag = torch.zeros(2, device=dev)      # exact_lagged: the GLOBAL range maxima of the previous step
+        self._lag_valid = False
         # "local": every rank normalises by its own mask sums, so the sum over ranks needs the 1/world of a mean of means
         k = 1.0 / _world(group) if eikonal_sync == "local" else 1.0
         self._igr = torch.tensor([self.igr_weight * k], device=dev)
@@ -221,18 +227,39 @@ class Trainer:
 
     def _ph_composite_bwd(self, S):
         sc_glob = S["scalars"]
-        if S["world"] > 1 and self.eikonal_sync == "exact":      # self._stats now holds the GLOBAL sums
+        exactish = self.eikonal_sync in ("exact", "exact_lagged")
+        if S["world"] > 1 and exactish:      # self._stats now holds the GLOBAL sums
             sc_glob = S["scalars"].clone()
             sc_glob[4], sc_glob[6] = self._stats[0], self._stats[1]
         S["sc_glob"] = sc_glob
         g = self.flat.grad
-        both = not (S["world"] > 1 and self.eikonal_sync == "exact")
+        both = not (S["world"] > 1 and exactish)
         self.r.backward_into(S["call"], S["v"], S["d_edge"], None, self._igr, self._igr_ns if self.igr_ns_weight != 0.0 else None,
                              flat=g[:self.flat.numel], scalars=sc_glob, stages=3 if both else 1)
         S["staged"] = not both
+        S["lagged"] = S["staged"] and self.eikonal_sync == "exact_lagged"
+        if S["lagged"]:
+            # The two range maxima of this rank go into its slots of the bucket's tail (the SUM all-reduce of the bucket then works as an
+            # all-gather of them: every other slot is zero) and become next step's GLOBAL maxima.  THIS step's sweep uses the previous
+            # step's global maxima x 4 (the kernel rounds to a power of two) instead of waiting for a MAX all-reduce - or the rank's own
+            # maxima where they exceed that, so that fp16 can never overflow: a rank whose gradients grew more than 4x in one step then
+            # differs from the others in rounding for that step only.  The first step (no history) takes the exact path.
+            cur = self.r.bwd_absmax(S["call"])
+            tail = self._maxima_tail()
+            tail.zero_()
+            rank = dist.get_rank(self.group)
+            tail[2 * rank:2 * rank + 2] = cur
+            if self._lag_valid:
+                cur.copy_(torch.maximum(self._lag * 4.0, cur))
+
+    def _maxima_tail(self):
+        n = self.flat.numel + self.N_STATS
+        return self.flat.grad[n:n + 2 * self.MAX_RANKS]
 
     def _ph_mlp_bwd(self, S):
         g = self.flat.grad
+        if S["lagged"] and not self._lag_valid:
+            self._lag.copy_(self.r.bwd_absmax(S["call"]))       # first step: the MAX all-reduce just ran; it seeds the history
         if S["staged"]:
             self.r.backward_into(S["call"], S["v"], S["d_edge"], None, self._igr, self._igr_ns if self.igr_ns_weight != 0.0 else None,
                                  flat=g[:self.flat.numel], scalars=S["sc_glob"], stages=2)
@@ -246,6 +273,10 @@ class Trainer:
         stats = self._stats
         if S["world"] > 1 and self.eikonal_sync == "local":
             stats = self.flat.grad[self.flat.numel:self.flat.numel + 5]
+        if S["lagged"]:
+            if self._lag_valid:      # the gathered per-rank maxima of THIS step -> next step's scale
+                self._lag.copy_(self._maxima_tail().view(self.MAX_RANKS, 2).max(dim=0).values)
+            self._lag_valid = True
         self.optimizer.step()      # frozen scalars are skipped inside the kernel (device mask, refresh_trainable_mask)
         self.r.udf_network.invalidate_packed()   # the flat update does not bump the per-parameter version counters
         out = torch.empty(2, device=dev)         # a fresh tensor per step: callers keep what step() returned
@@ -266,9 +297,10 @@ class Trainer:
         grad = ar(lambda S: self.flat.grad, dist.ReduceOp.SUM)
         if self.eikonal_sync == "local":
             return [(2, grad)]
-        return [(0, ar(lambda S: self._stats, dist.ReduceOp.SUM)),
-                (1, ar(lambda S: self.r.bwd_absmax(S["call"]), dist.ReduceOp.MAX)),
-                (2, grad)]
+        stats = (0, ar(lambda S: self._stats, dist.ReduceOp.SUM))
+        if self.eikonal_sync == "exact_lagged" and self._lag_valid:      # the maxima ride in the gradient bucket's tail
+            return [stats, (2, grad)]
+        return [stats, (1, ar(lambda S: self.r.bwd_absmax(S["call"]), dist.ReduceOp.MAX)), (2, grad)]
 
     def _step_native(self, rays: Dict, true_edge: torch.Tensor, n_rays_global: Optional[int]):
         S = {}
@@ -298,7 +330,7 @@ class Trainer:
         # stats: [sum(relax), sum(near), sum(relax*err), sum(near*err), sum(diff^2)] - scalars[3:7] = e_rel, c_rel, e_ns, c_ns
         stats = torch.cat([scalars[self._idx], (diff * diff).sum().reshape(1)])
         sc_glob = scalars
-        if world > 1 and self.eikonal_sync == "exact":
+        if world > 1 and self.eikonal_sync in ("exact", "exact_lagged"):      # (no fp16 range scale on this path: lagged = exact)
             dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=self.group)
             sc_glob = scalars.clone()
             sc_glob[4], sc_glob[6] = stats[0], stats[1]

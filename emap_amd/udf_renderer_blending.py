@@ -178,7 +178,7 @@ class UDFRendererBlending:
                 nf = (torch.full((N,), float(near), device=dev, dtype=torch.float32),
                       torch.full((N,), float(far), device=dev, dtype=torch.float32))
                 if len(self._const) > 16:       # bounded; never replaces a live entry in place (a captured graph may point at it)
-                    self._const.pop(next(k for k in self._const if k != "_scr"))
+                    self._const.pop(next(k for k in self._const if k not in ("_scr", "_jit")))
                 self._const[key] = nf
             near_t, far_t = nf
         else:
@@ -189,11 +189,29 @@ class UDFRendererBlending:
         if t_rand is not None:
             tr = _lib.f32c(t_rand.to(dev)).reshape(-1)
         elif perturb > 0:
-            tr = (torch.rand([N, 1]) - 0.5).to(dev).reshape(-1)   # the reference's CPU-generator draw (:719)
+            tr = self._jitter_draw(N, dev)                        # the reference's CPU-generator draw (:719)
         ds = _lib.f32c(depth_scale.detach().to(dev)).reshape(-1) if depth_scale is not None else None
         return {"N": N, "S": self.samples_per_ray, "dev": dev, "prec_name": prec_name, "ro": ro, "rd": rd, "near": near_t,
                 "far": far_t, "t_rand": tr, "ds": ds, "reduced": reduced,
                 "p": self._params(N, cos_anneal_ratio, flip_saturation, background_rgb)}
+
+    def _jitter_draw(self, N, dev):
+        """(torch.rand([N, 1]) - 0.5).to(dev) - the same values from the same CPU generator - through a small ring of pinned staging
+        buffers, so that the copy is asynchronous (a pageable host-to-device copy costs ~0.12 ms of host time per step).  A slot is
+        reused only after its copy has completed (event)."""
+        ring = self._const.get("_jit")
+        if ring is None or ring["N"] != N or ring["dev"] != dev:
+            ring = {"N": N, "dev": dev, "i": 0, "slots": [(torch.empty(N, 1).pin_memory(), torch.cuda.Event()) for _ in range(4)]}
+            self._const["_jit"] = ring
+        buf, ev = ring["slots"][ring["i"] % 4]
+        if ring["i"] >= 4:
+            ev.synchronize()
+        ring["i"] += 1
+        torch.rand([N, 1], out=buf)
+        buf.sub_(0.5)
+        tr = buf.to(dev, non_blocking=True).reshape(-1)
+        ev.record(torch.cuda.current_stream(dev))
+        return tr
 
     def _render_hip(self, call):
         """One emap_render_fwd call.  Returns the dict of flat output views (full: every per-sample entry of the
@@ -315,8 +333,10 @@ class UDFRendererBlending:
         return ws[off.value:off.value + 8].view(torch.float32)
 
     def _trainable(self):
-        ps = list(self.udf_network.parameters()) + [self.deviation_network.variance, self.beta_network.beta, self.beta_network.gamma]
-        return torch.is_grad_enabled() and any(q.requires_grad for q in ps)
+        if not torch.is_grad_enabled():
+            return False
+        lay = self._layout()       # its tensor list is checked against the modules' current parameters (ParamLayout.check) where it matters
+        return any(q.requires_grad for q in lay.tensors)
 
     def render(self, rays_o, rays_d, near, far, depth_scale, cos_anneal_ratio=None, perturb_overwrite=-1,
                background_rgb=None, flip_saturation=0, color_maps=None, pose=None, fx=None, fy=None, img_index=None,
@@ -401,7 +421,7 @@ class UDFRendererBlending:
         reduced-mode scratch, error word, packed weights, scratch of the UDF network): a captured graph keeps this list."""
         net = self.udf_network
         keep = [list(self._ws.values()), list(self._ws_pool.values()), list(self._bws.values()), self._err,
-                [v for k, v in self._const.items() if k != "_scr"], list(self._const.get("_scr", {}).values()),
+                [v for k, v in self._const.items() if k not in ("_scr", "_jit")], list(self._const.get("_scr", {}).values()),
                 [b for _, b in net._pack_cache.values()], list(net._vjp_ws.values()), list(net._scratch.values()), net._err]
         return keep
 

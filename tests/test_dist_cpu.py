@@ -144,7 +144,7 @@ def _launch(world, n_global, mode):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("mode", ["autograd", "exact"])
+@pytest.mark.parametrize("mode", ["autograd", "exact", "exact_lagged"])      # exact_lagged on the host path = exact (no fp16 range scale there)
 def test_two_rank_step_equals_single_process_step(mode):
     single = _launch(1, 16, mode)[0]
     two = _launch(2, 16, mode)
