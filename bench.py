@@ -38,6 +38,8 @@ import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+# the PMC passes of the dominant kernels recorded by scripts/profile_round.sh for this round's kernels (static: not measured in a bench run)
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r04_traffic.json")
 sys.path.insert(0, ROOT)
 
 F_POINT = 918016          # FLOP per MLP point-forward, d8 w256 (SURVEY par. 7.0 / 8d)
@@ -184,13 +186,13 @@ def train_key(dev, precision, rays, S, steps=40, warmup=10):
            "ms_per_step": dt * 1e3, "ms_per_step_median": med, "value": value, "unit": "ray-samples/s",
            "whole_step_algorithmic_tflops": value * A_TRAIN / 1e12, "whole_step_frac": value * A_TRAIN / 1e12 / MFMA_PEAK_TFLOPS,
            "launch": "eager", "loss_after_run": trainer.last_stats.tolist(), "traffic": None}
-    tpath = os.path.join(ROOT, "profiles", "r03_traffic.json")
+    tpath = TRAFFIC_JSON
     if os.path.exists(tpath) and rays * S == 65536:
         try:
             ent = json.load(open(tpath)).get(f"train:{precision}")
             if ent:
                 out["traffic"] = sum(ent.get("all", {}).values()) or ent.get("hbm_bytes_per_launch")
-                out["traffic_source"] = "STATIC: profiles/r03_traffic.json (sum over the step's MLP / weight-gradient kernels, rocprofv3 --pmc), not measured in this run"
+                out["traffic_source"] = f"STATIC: profiles/{os.path.basename(tpath)} (sum over the step's MLP / weight-gradient kernels, rocprofv3 --pmc), not measured in this run"
         except Exception:
             pass
     return out
@@ -677,7 +679,7 @@ def main():
             line["backward_kernels"] = bwd_us
         if parity is not None:
             line["parity"] = parity
-        tpath = os.path.join(ROOT, "profiles", "r03_traffic.json")
+        tpath = TRAFFIC_JSON
         if os.path.exists(tpath):
             try:
                 ent = json.load(open(tpath)).get(f"{a.mode}:{a.precision}")
@@ -686,7 +688,7 @@ def main():
                 same_launch = rays * S == 65536
                 if ent and same_launch:
                     line["roofline"]["traffic"] = ent["hbm_bytes_per_launch"]
-                    line["roofline"]["traffic_source"] = ("STATIC: profiles/r03_traffic.json, recorded by rocprofv3 --pmc passes of this kernel at this launch "
+                    line["roofline"]["traffic_source"] = (f"STATIC: profiles/{os.path.basename(tpath)}, recorded by rocprofv3 --pmc passes of this kernel at this launch "
                                                           "size (scripts/profile_round.sh; MI355X_MICROARCH.md corrections), not measured in this run")
             except Exception:
                 pass
