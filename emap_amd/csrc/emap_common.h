@@ -59,6 +59,7 @@ struct NetLayout {
     int32_t total_frags;
     int32_t bias_off_bytes, rowscale_off_bytes, frag_off_bytes;
     int32_t is_f16;
+    int32_t mx_fwd;            // EMAP_PREC_F16X3M: the forward 32x32 section (r32) in the mixed MX layout too
     // transposed section (reverse-mode d(udf)/dx, udf_mlp_rev_kernel): W_l^T fragments for the backward GEMMs
     //   t_off[l]   first fragment of layer l's hidden-row block  [row pair][K-step over out features][t][part], l >= 1
     //   tpe_off[l] first fragment of layer l's PE-row block      [pe pair 0..1][K-step][t][part], l in {0, skip_l}
@@ -78,6 +79,12 @@ struct NetLayout {
 #define EMAP_REV_MX6 1      // 0: f16 cross terms in the backward GEMMs too (A/B builds: compile udf_mlp AND udf_mlp_f16x3 with the flag)
 #endif
 __host__ __device__ inline bool r32_t_mixed(const NetLayout& L) { return EMAP_REV_MX6 && L.is_f16 && L.nparts == 2 && L.H == 256; }
+// The same for the FORWARD sweep of that kernel (udf_mlp.hip:pack32_body writes the mixed layout too): precision mode EMAP_PREC_F16X3M.
+__host__ __device__ inline bool r32_mixed(const NetLayout& L) { return L.mx_fwd && r32_t_mixed(L); }
+// fixed MX scales of the positional-encoding block (|sin|, |cos| <= 1, raw coordinates up to 1.875 exactly): 2^-2 for the hi parts,
+// 2^-3 for the lo parts (x 2^11 in f16, undone in the E8M0 byte)
+#define EMAP_PE_HI6_E8M0 125u
+#define EMAP_PE_LO6_E8M0 124u
 // E8M0 scale of an MX block of e2m3 values with largest magnitude m, as the exponent field of an fp32 (bits 23..30):
 // 2^(floor(log2(m * 8/7.5)) - 2), so that m / scale <= 7.5 (the e2m3 maximum)
 __host__ __device__ inline uint32_t mx6_scale_bits(float m) {
@@ -175,7 +182,8 @@ long long* prof_clk_here();   // g_prof_clk if the current device is the one it 
 extern long long* g_prof_clk;   // device buffer of 8 x int64 while emap_profile_enable(1) is in effect, else null (clock_stamp in udf_mlp_kernel.inc)
 constexpr int REV_MAX_WG = 768;      // persistent workgroups of the reverse-mode kernel (3 per CU)
 inline size_t rev_scratch_bytes(const NetLayout& L) {   // sigmoid stash: [workgroup][layer][pair][4][64 lanes x 16 B]
-    return L.has_rev ? (size_t)(REV_MAX_WG * 2 / 3) * (size_t)(L.n_lin - 1) * (size_t)(L.H / 32) * 4096 : 0;   // 2 resident workgroups per CU
+    // + 8 KiB per workgroup: the lo parts of the tile's PE block (MX6F: their LDS slots hold the fp6 forms; read back by the PE rows)
+    return L.has_rev ? (size_t)(REV_MAX_WG * 2 / 3) * ((size_t)(L.n_lin - 1) * (size_t)(L.H / 32) * 4096 + 8192) : 0;   // 2 resident workgroups per CU
 }
 
 }  // namespace emap

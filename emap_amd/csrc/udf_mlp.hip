@@ -19,7 +19,7 @@ long long* prof_clk_here() {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-__host__ __device__ constexpr bool prec_is_f16(int mode) { return mode == EMAP_PREC_F16 || mode == EMAP_PREC_F16X3; }
+__host__ __device__ constexpr bool prec_is_f16(int mode) { return mode == EMAP_PREC_F16 || mode == EMAP_PREC_F16X3 || mode == EMAP_PREC_F16X3M; }
 __host__ __device__ constexpr int prec_nparts(int mode) { return (mode == EMAP_PREC_BF16 || mode == EMAP_PREC_F16) ? 1 : 2; }
 
 // ---------------------------------------------------------------------------------------------
@@ -218,6 +218,55 @@ __device__ __forceinline__ void store_frag(const PackArgs& a, char* dst, const f
     else *reinterpret_cast<bf16x8*>(dst) = outv;
 }
 
+typedef _Float16 f16x32 __attribute__((ext_vector_type(32)));
+typedef uint32_t u32x6 __attribute__((ext_vector_type(6)));
+
+// The 8 KiB block of one (row tile, K64-step Sg) in the MIXED layout of the MX-fp6 sweeps, written by the eight threads f = 0..7 of a lane;
+// weight(S, u, e) = the element of K32-step S, K16-step u, k-slot e of this lane's row.  Layout: see pack32_t_body.
+template <class WF>
+__device__ __forceinline__ void store_mixed_block(const PackArgs& a, char* blk, int lane, int f, int Sg, int NSG, WF&& weight) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    if (f < 4) {
+        float w[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) w[e] = weight(2 * Sg + (f >> 1), f & 1, e);
+        store_frag(a, blk + f * FRAG_BYTES + lane * 16, w, 0);
+        return;
+    }
+    // the lane's fp6 block of K64-step sg: its six registers and its E8M0 byte
+    auto block6 = [&](int sg, int part6, u32x6& q) -> uint32_t {
+        f16x32 v;
+        float m = 0.f;
+#pragma unroll
+        for (int e = 0; e < 32; ++e) {
+            const float w = weight(2 * sg + (e >> 4), (e >> 3) & 1, e & 7);
+            const _Float16 h16 = (_Float16)w;
+            const _Float16 x = (part6 == 0) ? h16 : (_Float16)((w - (float)h16) * 2048.0f);
+            v[e] = x;
+            m = fmaxf(m, fabsf((float)x));
+        }
+        const uint32_t sb = mx6_scale_bits(m);
+        q = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(v, __builtin_bit_cast(float, sb));
+        return (sb >> 23) - (part6 ? 11u : 0u);
+    };
+    u32x6 q;
+    if (f == 4 || f == 5) {
+        block6(Sg, f - 4, q);
+        *reinterpret_cast<u32x4*>(blk + f * FRAG_BYTES + lane * 16) = u32x4{q[0], q[1], q[2], q[3]};
+    } else if (f == 6) {
+        block6(Sg, 0, q);
+        *reinterpret_cast<u32x2*>(blk + 6 * FRAG_BYTES + lane * 8) = u32x2{q[4], q[5]};
+        block6(Sg, 1, q);
+        *reinterpret_cast<u32x2*>(blk + 6 * FRAG_BYTES + 512 + lane * 8) = u32x2{q[4], q[5]};
+    } else {
+        uint32_t sc[2] = {0u, 0u};
+        for (int j = 0; j < 4 && Sg + j < NSG; ++j)
+            for (int part6 = 0; part6 < 2; ++part6) sc[j >> 1] |= (block6(Sg + j, part6, q) & 255u) << (8 * (2 * (j & 1) + part6));
+        *reinterpret_cast<u32x2*>(blk + 7 * FRAG_BYTES + lane * 8) = u32x2{sc[0], sc[1]};
+    }
+}
+
 __device__ __forceinline__ void pack32_body(const PackArgs& a, unsigned block) {
     const long long gid = (long long)block * 256 + threadIdx.x;  // one thread per (fragment, lane)
     const long long F = gid >> 6;
@@ -228,19 +277,13 @@ __device__ __forceinline__ void pack32_body(const PackArgs& a, unsigned block) {
     const LayerDesc Ld = a.L.layer[l];
     const int H = a.L.H, NP = a.L.nparts, d0 = a.L.d0, M = a.L.multires;
     int idx = (int)(F - Ld.frag_off);
-    const int part = idx % NP; idx /= NP;
-    const int u = idx & 1; idx >>= 1;
     const int n_ks = Ld.pe_ks + Ld.h_ks;
-    const int S = idx % n_ks;
-    const int p = idx / n_ks;
     const int i = lane & 31, hh = lane >> 5;
-    const int o = 32 * p + i;
     const float* rs = reinterpret_cast<const float*>(a.packed + a.L.rowscale_off_bytes);
     const float mult = (l == a.L.skip_l) ? 0.70710678118654752440f : 1.0f;  // cat([x, PE]) / sqrt(2), udf_model.py:100
     const int n_in = a.in_dim[l];
-    float w[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
+    // element (K32-step S, K16-step u, k-slot e) of row o
+    auto weight = [&](int o, int S, int u, int e) -> float {
         int col = -1;
         if (S < Ld.pe_ks) {
             const int pcol = pe_col_of(16 * hh + 8 * S + 4 * u + (e >> 1), e & 1, M, d0);
@@ -249,13 +292,26 @@ __device__ __forceinline__ void pack32_body(const PackArgs& a, unsigned block) {
             const int f = 32 * (S - Ld.pe_ks) + (e & 3) + 8 * (2 * u + (e >> 2)) + 4 * hh;
             if (f < Ld.in_prev) col = f;
         }
-        w[e] = (o < Ld.out_dim && col >= 0 && col < n_in) ? rs[l * H + o] * a.v[l][(size_t)o * n_in + col] * mult : 0.f;
+        return (o < Ld.out_dim && col >= 0 && col < n_in) ? rs[l * H + o] * a.v[l][(size_t)o * n_in + col] * mult : 0.f;
+    };
+    if (r32_mixed(a.L)) {      // MX-fp6 forward sweep: one 8 KiB block per (row tile, K64-step) - every layer has an even number of K32-steps
+        const int f = idx & 7; idx >>= 3;
+        const int NSG = n_ks / 2;
+        const int Sg = idx % NSG;
+        const int o = 32 * (idx / NSG) + i;
+        store_mixed_block(a, a.packed + a.L.r32_frag_off_bytes + (F - f) * FRAG_BYTES, lane, f, Sg, NSG,
+                          [&](int S, int u, int e) -> float { return weight(o, S, u, e); });
+        return;
     }
+    const int part = idx % NP; idx /= NP;
+    const int u = idx & 1; idx >>= 1;
+    const int S = idx % n_ks;
+    const int o = 32 * (idx / n_ks) + i;
+    float w[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) w[e] = weight(o, S, u, e);
     store_frag(a, a.packed + a.L.r32_frag_off_bytes + F * FRAG_BYTES + lane * 16, w, part);
 }
-
-typedef _Float16 f16x32 __attribute__((ext_vector_type(32)));
-typedef uint32_t u32x6 __attribute__((ext_vector_type(6)));
 
 // Transposed fragments of the 32x32x16 reverse sweep: A operand of  delta_in = W_l^T * delta_z_l.
 //   hidden rows: row i of row tile p is input feature 32p + i of layer l (natural order = the A-operand row, so the C
@@ -328,49 +384,9 @@ __device__ __forceinline__ void pack32_t_body(const PackArgs& a, unsigned block)
     const int f = idx & 7; idx >>= 3;
     const int NSG = NKS / 2;
     const int Sg = idx % NSG;
-    const int p = idx / NSG;
-    const int col = col_of(p);
-    if (f < 4) {
-        float w[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) w[e] = weight(col, 2 * Sg + (f >> 1), f & 1, e);
-        store_frag(a, dst, w, 0);
-        return;
-    }
-    // the lane's fp6 block of K64-step sg: its six registers and its E8M0 byte
-    auto block6 = [&](int sg, int part6, u32x6& q) -> uint32_t {
-        f16x32 v;
-        float m = 0.f;
-#pragma unroll
-        for (int e = 0; e < 32; ++e) {
-            const float w = weight(col, 2 * sg + (e >> 4), (e >> 3) & 1, e & 7);
-            const _Float16 h16 = (_Float16)w;
-            const _Float16 x = (part6 == 0) ? h16 : (_Float16)((w - (float)h16) * 2048.0f);
-            v[e] = x;
-            m = fmaxf(m, fabsf((float)x));
-        }
-        const uint32_t sb = mx6_scale_bits(m);
-        q = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(v, __builtin_bit_cast(float, sb));
-        return (sb >> 23) - (part6 ? 11u : 0u);
-    };
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-    char* blk = a.packed + a.L.r32_t_frag_off_bytes + (F - f) * FRAG_BYTES;
-    u32x6 q;
-    if (f == 4 || f == 5) {
-        block6(Sg, f - 4, q);
-        *reinterpret_cast<u32x4*>(dst) = u32x4{q[0], q[1], q[2], q[3]};
-    } else if (f == 6) {
-        block6(Sg, 0, q);
-        *reinterpret_cast<u32x2*>(blk + 6 * FRAG_BYTES + lane * 8) = u32x2{q[4], q[5]};
-        block6(Sg, 1, q);
-        *reinterpret_cast<u32x2*>(blk + 6 * FRAG_BYTES + 512 + lane * 8) = u32x2{q[4], q[5]};
-    } else {
-        uint32_t sc[2] = {0u, 0u};
-        for (int j = 0; j < 4 && Sg + j < NSG; ++j)
-            for (int part6 = 0; part6 < 2; ++part6) sc[j >> 1] |= (block6(Sg + j, part6, q) & 255u) << (8 * (2 * (j & 1) + part6));
-        *reinterpret_cast<u32x2*>(blk + 7 * FRAG_BYTES + lane * 8) = u32x2{sc[0], sc[1]};
-    }
+    const int col = col_of(idx / NSG);
+    store_mixed_block(a, a.packed + a.L.r32_t_frag_off_bytes + (F - f) * FRAG_BYTES, lane, f, Sg, NSG,
+                      [&](int S, int u, int e) -> float { return weight(col, S, u, e); });
 }
 
 // fp32 copy of the last layer's real row (times its weight-norm scale): the seed of the reverse sweep
@@ -393,12 +409,17 @@ int build_layout(const EmapNetConfig* cfg, int prec, NetLayout* L) {
     if (cfg->n_lin < 2 || cfg->n_lin > EMAP_MAX_LIN) { set_error("n_lin out of range (%d)", cfg->n_lin); return EMAP_E_INVALID; }
     if (cfg->multires < 1 || cfg->multires > 10) { set_error("multires must be in 1..10 (got %d)", cfg->multires); return EMAP_E_INVALID; }
     if (cfg->d_out != 1) { set_error("d_out must be 1 (got %d): feature outputs are not on the hot path", cfg->d_out); return EMAP_E_INVALID; }
-    if (prec < EMAP_PREC_BF16 || prec > EMAP_PREC_F16X3) { set_error("unknown precision mode %d", prec); return EMAP_E_INVALID; }
+    if (prec < EMAP_PREC_BF16 || prec > EMAP_PREC_F16X3M) { set_error("unknown precision mode %d", prec); return EMAP_E_INVALID; }
+    if (prec == EMAP_PREC_F16X3M && (cfg->d_hidden != 256 || !EMAP_REV_MX6)) {
+        set_error("precision f16x3m (MX fp6 cross terms in the forward sweep) needs d_hidden = 256 (got %d)", cfg->d_hidden);
+        return EMAP_E_INVALID;
+    }
     if (cfg->skip_l == 0 || cfg->skip_l == 1 || cfg->skip_l >= cfg->n_lin) { set_error("unsupported skip layer %d", cfg->skip_l); return EMAP_E_INVALID; }
     if (!(cfg->scale > 0.f)) { set_error("scale must be > 0"); return EMAP_E_INVALID; }
     const int H = cfg->d_hidden;
     L->H = H; L->n_lin = cfg->n_lin; L->skip_l = cfg->skip_l; L->multires = cfg->multires;
     L->d0 = 3 + 6 * cfg->multires; L->nparts = prec_nparts(prec); L->is_f16 = prec_is_f16(prec) ? 1 : 0;
+    L->mx_fwd = (prec == EMAP_PREC_F16X3M) ? 1 : 0;
     L->udf_type = cfg->udf_type; L->scale = cfg->scale;
     int frag = 0, chunks = 0;
     for (int l = 0; l < cfg->n_lin; ++l) {
@@ -506,7 +527,7 @@ int set_grad_mode(int mode) {
 static int mlp_variant(const NetLayout& L, int prec, int64_t P, bool grad) {
     // reverse mode halves the MFMA work of a grad launch but a tile is two dependent sweeps: it wins once most CUs have a
     // workgroup (measured crossover: the split modes between 8k and 12k points, single-pass modes at 16k).
-    const int64_t rev_min = (prec == EMAP_PREC_F16X3 || prec == EMAP_PREC_BF16X3) ? 10240 : 16384;
+    const int64_t rev_min = (prec == EMAP_PREC_F16X3 || prec == EMAP_PREC_F16X3M || prec == EMAP_PREC_BF16X3) ? 10240 : 16384;
     const int gm = g_grad_mode;
     if (grad && L.has_rev && gm != 0 && (P >= rev_min || gm == 1)) return 3;
     return 2;
@@ -521,7 +542,8 @@ int launch_mlp(const NetLayout& L, const void* packed, int prec, const PointSour
         case EMAP_PREC_BF16: return launch_mlp_bf16(L, packed, src, P, udf, grad3, st, v, err_flags, scratch);
         case EMAP_PREC_BF16X3: return launch_mlp_bf16x3(L, packed, src, P, udf, grad3, st, v, err_flags, scratch);
         case EMAP_PREC_F16: return launch_mlp_f16(L, packed, src, P, udf, grad3, st, v, err_flags, scratch);
-        case EMAP_PREC_F16X3: return launch_mlp_f16x3(L, packed, src, P, udf, grad3, st, v, err_flags, scratch);
+        case EMAP_PREC_F16X3:
+        case EMAP_PREC_F16X3M: return launch_mlp_f16x3(L, packed, src, P, udf, grad3, st, v, err_flags, scratch);   // L.mx_fwd selects the kernel
     }
     set_error("unknown precision mode %d", prec);
     return EMAP_E_INVALID;

@@ -72,7 +72,8 @@ def get_udf_normals_grid(func, func_grad, N, udf_threshold, is_linedirection=Fal
         raise RuntimeError("emap_amd.extraction runs on the GPU only (no CPU fallback)")
     net = _fast_net(func, func_grad)
     # the N^3 lattice on [-1, 1]^3, first coordinate slowest (the reference's point order and fp32 arithmetic, :36-54: index * 2/(N-1) - 1)
-    axis = torch.arange(N, device=device, dtype=torch.float32) * (2.0 / (N - 1)) + (-1)
+    voxel_size = 2.0 / (N - 1)
+    axis = torch.arange(N, device=device, dtype=torch.float32) * voxel_size + (-1)
     samples = torch.zeros(N ** 3, 12, device=device)
     samples[:, :3] = torch.stack(torch.meshgrid(axis, axis, axis, indexing="ij"), dim=-1).reshape(-1, 3)
 

@@ -13,5 +13,5 @@ python - "$OUT" <<'PY'
 import json, sys
 for l in open(sys.argv[1]):
     d = json.loads(l); b = d["line"]
-    print(d["variant"], d["round"], "ms/step %.4f" % b["ms_per_step"], "kernel us %.1f" % b["roofline"]["avg_launch_us"], "frac %.4f" % b["roofline"]["frac"])
+    print(d["variant"], d["round"], "ms/step %.4f" % b["ms_per_step"], "kernel us %.1f" % b["roofline"]["avg_launch_us"], "frac %.4f" % b["roofline"]["frac"], "clock MHz", b["roofline"].get("shader_clock_mhz"))
 PY
