@@ -323,3 +323,51 @@ def test_mode_f16x3m_meets_the_gate_with_its_own_recorded_margin():
         e = rel(o[k], torch.from_numpy(g5["out." + k]))
         print("f16x3m render", k, e)
         assert e <= 1e-4, k
+
+
+def test_mode_f16x3m_trains_like_f16x3():
+    """The training path takes the mode too: forward in f16x3m, backward kernels as f16x3 (include/emap_hip.h) - gradients of one
+    Trainer step agree with the f16x3 step's far inside the 1e-3 gate of the training gradients."""
+    from conftest import net_state
+    kw, state = net_state("d8w256L10")
+    ro, rd, near, far, ds = synthetic.make_rays(256, seed=11)
+    te = synthetic.make_true_edge(256, seed=12).to(DEV)
+    tr = synthetic.make_t_rand(256, seed=13).to(DEV)
+    grads = {}
+    for prec in ("f16x3", "f16x3m"):
+        n = emap_amd.UDFNetwork(precision=prec, **kw)
+        n.load_state_dict(state)
+        n = n.to(DEV)
+        devn = emap_amd.SingleVarianceNetwork(0.3).to(DEV)
+        bet = emap_amd.BetaNetwork(0.5, 0.3, 0.3, 5e-5, True, True, False).to(DEV)
+        r = emap_amd.UDFRendererBlending(None, n, devn, bet, 64, 64, 0, 4, 1.0, device=DEV)
+        t_ = Trainer(r, lr_geo=1e-3, lr=5e-3, igr_weight=0.1, igr_ns_weight=0.05)
+        batch = dict(rays_o=ro.to(DEV), rays_d=rd.to(DEV), near=near.to(DEV), far=far.to(DEV), depth_scale=ds.to(DEV),
+                     cos_anneal_ratio=1.0, flip_saturation=0.9, t_rand=tr)
+        stats = t_.step(batch, te)
+        torch.cuda.synchronize()
+        r.check_errors()
+        assert torch.isfinite(stats).all()
+        grads[prec] = t_.flat.grad[:t_.flat.numel].clone()
+    e = rel(grads["f16x3m"], grads["f16x3"])
+    print("dL/dtheta, f16x3m step vs f16x3 step: max abs diff / max |g| =", e)
+    assert e <= 5e-4
+
+
+def test_jitter_draw_is_the_reference_cpu_draw():
+    """render() without t_rand draws (torch.rand([N, 1]) - 0.5) on the CPU generator like the reference (udf_renderer_blending.py:719); the
+    pinned staging ring must hand the kernels exactly those values, call after call."""
+    from conftest import net_state
+    kw, state = net_state("d4w128L10")
+    n = emap_amd.UDFNetwork(precision="f16x3", **kw)
+    n.load_state_dict(state)
+    n = n.to(DEV)
+    devn = emap_amd.SingleVarianceNetwork(0.3).to(DEV)
+    bet = emap_amd.BetaNetwork(0.5, 0.3, 0.3, 5e-5, True, True, False).to(DEV)
+    r = emap_amd.UDFRendererBlending(None, n, devn, bet, 16, 16, 0, 2, 1.0, device=DEV)
+    torch.manual_seed(123)
+    ref = [(torch.rand([40, 1]) - 0.5) for _ in range(7)]
+    torch.manual_seed(123)
+    got = [r._jitter_draw(40, torch.device(DEV)).cpu().reshape(40, 1) for _ in range(7)]
+    for a_, b_ in zip(ref, got):
+        assert torch.equal(a_, b_)
