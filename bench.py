@@ -47,7 +47,7 @@ A_FWD = 2639296           # algorithmic FLOP per ray-sample of a forward render 
 A_TRAIN = 6311360         # ... of a training step
 MODE_DTYPE = {
     "f16x3": "f16x3 (split-fp16 MFMA, 3 passes, fp32 accumulate)",
-    "f16x3m": "f16x3m (f16x3 with MX-fp6 cross terms in the forward sweep of the value+gradient pass too; gradient error 8.7e-5 of the 1e-4 gate)",
+    "f16x3m": "f16x3m (f16x3 with MX-fp6 cross terms in the forward sweep of the value+gradient pass too; gradient error 6.2e-5 of the 1e-4 gate)",
     "bf16x3": "bf16x3 (split-bf16 MFMA, 3 passes, fp32 accumulate)",
     "f16": "f16 (single-pass fp16 MFMA, fp32 accumulate)",
     "bf16": "bf16 (single-pass bf16 MFMA, fp32 accumulate)",

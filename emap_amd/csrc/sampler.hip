@@ -595,9 +595,12 @@ struct CompositeBwdArgs {
     uint32_t* absmax;                   // [2]: max|d_udf|, max|d_grad| (atomicMax), may be null
 };
 
+// MS = capacity of the 13 per-ray LDS arrays: 128 for S <= 128 (6.5 KiB per ray: 24 rays resident per CU, so that 4096 rays - 16 per CU - run
+// in one round; with 256 everywhere the 13 KiB per ray allowed 12 and the 4096-ray backward took two rounds), else 256
+template <int MS>
 __global__ __launch_bounds__(64) void composite_bwd_kernel(const CompositeBwdArgs a) {
-    __shared__ float s_z[MAXS], s_tc[MAXS], s_eq[MAXS], s_ain[MAXS], s_a[MAXS], s_vp[MAXS], s_ap[MAXS], s_am[MAXS], s_om[MAXS],
-        s_T[MAXS], s_x[MAXS], s_suf[MAXS], s_dal[MAXS];
+    __shared__ float s_z[MS], s_tc[MS], s_eq[MS], s_ain[MS], s_a[MS], s_vp[MS], s_ap[MS], s_am[MS], s_om[MS],
+        s_T[MS], s_x[MS], s_suf[MS], s_dal[MS];
     const int ray = blockIdx.x, lane = threadIdx.x, S = a.S;
     const float ox = a.rays_o[3 * ray], oy = a.rays_o[3 * ray + 1], oz = a.rays_o[3 * ray + 2];
     const float dx = a.rays_d[3 * ray], dy = a.rays_d[3 * ray + 1], dz = a.rays_d[3 * ray + 2];
@@ -872,7 +875,8 @@ int launch_composite_bwd(const float* rays_o, const float* rays_d, const float* 
     a.scalars = gr->scalars; a.d_udf = d_udf; a.d_grad = d_grad3; a.partials = partials; a.absmax = absmax;
     if ((a.d_ge || a.d_ge_ns) && !a.scalars) { set_error("composite_bwd: the eikonal gradients need the forward's scalars"); return EMAP_E_INVALID; }
     if (absmax && hipMemsetAsync(absmax, 0, 8, st) != hipSuccess) { set_error("hipMemsetAsync failed"); return EMAP_E_LAUNCH; }
-    hipLaunchKernelGGL(composite_bwd_kernel, dim3(N), dim3(64), 0, st, a);
+    if (S <= 128) hipLaunchKernelGGL(composite_bwd_kernel<128>, dim3(N), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL(composite_bwd_kernel<MAXS>, dim3(N), dim3(64), 0, st, a);
     hipLaunchKernelGGL(composite_bwd_reduce_kernel, dim3(1), dim3(256), 0, st, partials, N, a, gr->d_variance, gr->d_beta,
                        gr->d_gamma, gr->grad_scale, gr->accumulate);
     return check_launch("composite_bwd");

@@ -221,49 +221,56 @@ __device__ __forceinline__ void store_frag(const PackArgs& a, char* dst, const f
 typedef _Float16 f16x32 __attribute__((ext_vector_type(32)));
 typedef uint32_t u32x6 __attribute__((ext_vector_type(6)));
 
-// The 8 KiB block of one (row tile, K64-step Sg) in the MIXED layout of the MX-fp6 sweeps, written by the eight threads f = 0..7 of a lane;
-// weight(S, u, e) = the element of K32-step S, K16-step u, k-slot e of this lane's row.  Layout: see pack32_t_body.
+// The 8 KiB block of one (row tile, K64-step Sg) in the MIXED layout of the MX-fp6 sweeps (layout: see pack32_t_body), written by thread f = 0 of
+// each lane - the fragment-granular grid of pack_all_kernel gives a block eight waves, seven of them exit: one thread evaluates the lane's 32
+// weights ONCE and writes everything derived from them (the first version spread the block over the eight threads, each recomputing the block
+// maxima: 416 weight evaluations per lane and block instead of 32, and the re-pack of a training step took 154 us instead of 17).
+// weight(S, u, e) = the element of K32-step S, K16-step u, k-slot e of this lane's row.
 template <class WF>
 __device__ __forceinline__ void store_mixed_block(const PackArgs& a, char* blk, int lane, int f, int Sg, int NSG, WF&& weight) {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-    if (f < 4) {
-        float w[8];
+    if (f != 0) return;
+    f16x32 vh, vl;
+    float mh = 0.f, ml = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) w[e] = weight(2 * Sg + (f >> 1), f & 1, e);
-        store_frag(a, blk + f * FRAG_BYTES + lane * 16, w, 0);
-        return;
+    for (int e = 0; e < 32; ++e) {       // element order of the lane's MX block: e = 16 t + 8 u + e'  <->  (S = 2 Sg + t, u, e')
+        const float w = weight(2 * Sg + (e >> 4), (e >> 3) & 1, e & 7);
+        const _Float16 h16 = (_Float16)w;
+        const _Float16 l16 = (_Float16)((w - (float)h16) * 2048.0f);
+        vh[e] = h16; vl[e] = l16;
+        mh = fmaxf(mh, fabsf((float)h16));
+        ml = fmaxf(ml, fabsf((float)l16));
     }
-    // the lane's fp6 block of K64-step sg: its six registers and its E8M0 byte
-    auto block6 = [&](int sg, int part6, u32x6& q) -> uint32_t {
-        f16x32 v;
-        float m = 0.f;
+    // @0..3 KiB: the four hi16 fragments (t, u)
+    typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
 #pragma unroll
-        for (int e = 0; e < 32; ++e) {
-            const float w = weight(2 * sg + (e >> 4), (e >> 3) & 1, e & 7);
-            const _Float16 h16 = (_Float16)w;
-            const _Float16 x = (part6 == 0) ? h16 : (_Float16)((w - (float)h16) * 2048.0f);
-            v[e] = x;
-            m = fmaxf(m, fabsf((float)x));
+    for (int q = 0; q < 4; ++q) {
+        f16x8v o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = vh[8 * q + e];
+        *reinterpret_cast<f16x8v*>(blk + q * FRAG_BYTES + lane * 16) = o;
+    }
+    // fp6 forms and their E8M0 bytes (lo parts are stored x 2^11: undone in the byte)
+    const uint32_t sbh = mx6_scale_bits(mh), sbl = mx6_scale_bits(ml);
+    const u32x6 qh = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(vh, __builtin_bit_cast(float, sbh));
+    const u32x6 ql = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(vl, __builtin_bit_cast(float, sbl));
+    *reinterpret_cast<u32x4*>(blk + 4 * FRAG_BYTES + lane * 16) = u32x4{qh[0], qh[1], qh[2], qh[3]};
+    *reinterpret_cast<u32x4*>(blk + 5 * FRAG_BYTES + lane * 16) = u32x4{ql[0], ql[1], ql[2], ql[3]};
+    *reinterpret_cast<u32x2*>(blk + 6 * FRAG_BYTES + lane * 8) = u32x2{qh[4], qh[5]};
+    *reinterpret_cast<u32x2*>(blk + 6 * FRAG_BYTES + 512 + lane * 8) = u32x2{ql[4], ql[5]};
+    // @7 KiB of block Sg' (8 B / lane): bytes 2 j + (hi6 | lo6) = the scales of step Sg' + j, j = 0..3.  This thread owns the bytes of ITS step in
+    // the slots of blocks Sg, Sg - 1, Sg - 2, Sg - 3 (byte stores) and zeroes the bytes of its own slot that belong to no step
+    const uint8_t bh = (uint8_t)(sbh >> 23), bl = (uint8_t)((sbl >> 23) - 11u);
+    for (int j = 0; j < 4; ++j) {
+        if (Sg - j >= 0) {
+            uint8_t* slot = reinterpret_cast<uint8_t*>(blk - (ptrdiff_t)j * 8 * FRAG_BYTES + 7 * FRAG_BYTES + lane * 8);
+            slot[2 * j] = bh; slot[2 * j + 1] = bl;
         }
-        const uint32_t sb = mx6_scale_bits(m);
-        q = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(v, __builtin_bit_cast(float, sb));
-        return (sb >> 23) - (part6 ? 11u : 0u);
-    };
-    u32x6 q;
-    if (f == 4 || f == 5) {
-        block6(Sg, f - 4, q);
-        *reinterpret_cast<u32x4*>(blk + f * FRAG_BYTES + lane * 16) = u32x4{q[0], q[1], q[2], q[3]};
-    } else if (f == 6) {
-        block6(Sg, 0, q);
-        *reinterpret_cast<u32x2*>(blk + 6 * FRAG_BYTES + lane * 8) = u32x2{q[4], q[5]};
-        block6(Sg, 1, q);
-        *reinterpret_cast<u32x2*>(blk + 6 * FRAG_BYTES + 512 + lane * 8) = u32x2{q[4], q[5]};
-    } else {
-        uint32_t sc[2] = {0u, 0u};
-        for (int j = 0; j < 4 && Sg + j < NSG; ++j)
-            for (int part6 = 0; part6 < 2; ++part6) sc[j >> 1] |= (block6(Sg + j, part6, q) & 255u) << (8 * (2 * (j & 1) + part6));
-        *reinterpret_cast<u32x2*>(blk + 7 * FRAG_BYTES + lane * 8) = u32x2{sc[0], sc[1]};
+        if (Sg + j >= NSG) {
+            uint8_t* own = reinterpret_cast<uint8_t*>(blk + 7 * FRAG_BYTES + lane * 8);
+            own[2 * j] = 0; own[2 * j + 1] = 0;
+        }
     }
 }
 

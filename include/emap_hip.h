@@ -48,7 +48,7 @@ extern "C" {
 #define EMAP_PREC_F16X3 3       /* split fp16, three passes (~2^-22): the mode of the 1e-4 parity gate */
 #define EMAP_PREC_F16X3M 4      /* EMAP_PREC_F16X3 with the cross terms of the value+gradient pass's FORWARD sweep as MX fp6 too (its
                                    reverse sweep has them in every split-fp16 build): d_hidden = 256 only; the kernel ~10 % faster,
-                                   grad_x 8.7e-5 instead of 3.0e-5 of the 1e-4 gate (DESIGN.md par. 6c); every other kernel = F16X3 */
+                                   grad_x 6.2e-5 instead of 3.0e-5 of the 1e-4 gate (DESIGN.md par. 6c); every other kernel = F16X3 */
 
 /* udf_type (udf_model.py:82-88) */
 #define EMAP_UDF_ABS 0
