@@ -595,8 +595,8 @@ struct CompositeBwdArgs {
     uint32_t* absmax;                   // [2]: max|d_udf|, max|d_grad| (atomicMax), may be null
 };
 
-// MS = capacity of the 13 per-ray LDS arrays: 128 for S <= 128 (6.5 KiB per ray: 24 rays resident per CU, so that 4096 rays - 16 per CU - run
-// in one round; with 256 everywhere the 13 KiB per ray allowed 12 and the 4096-ray backward took two rounds), else 256
+// MS = capacity of the 13 per-ray LDS arrays: 128 for S <= 128 (6.5 KiB per ray: 24 rays resident per CU instead of 12), else 256.  Measured at
+// 4096 rays (16 per CU): 108.6 us either way - with four rays per SIMD the kernel is bound by its instruction count, not by residency (round 4)
 template <int MS>
 __global__ __launch_bounds__(64) void composite_bwd_kernel(const CompositeBwdArgs a) {
     __shared__ float s_z[MS], s_tc[MS], s_eq[MS], s_ain[MS], s_a[MS], s_vp[MS], s_ap[MS], s_am[MS], s_om[MS],
