@@ -29,11 +29,12 @@ from oracle import emap_oracle as O  # noqa: E402
 from oracle import vjp_mirror as M  # noqa: E402
 
 
-def sweep(state, cfg, x, du, dg, passes):
+def sweep(state, cfg, x, du, dg, passes, passes_bwd=None):
     """The recurrences of WG.operands with every GEMM through MX.gemm(W, x, passes) (fp32 emulation); passes = None: fp64 exact."""
     dt = torch.float64 if passes is None else torch.float32
     Ws, bs = O._weights(state, cfg, dt)
     mm = (lambda W, v: v @ W.t()) if passes is None else (lambda W, v: MX.gemm(W.contiguous(), v.contiguous(), passes))
+    mmb = mm if passes_bwd is None else (lambda W, v: MX.gemm(W.contiguous(), v.contiguous(), passes_bwd))      # the backward GEMMs (W^T)
     xs = (x * cfg.scale).to(dt)
     pe, dpe = M.pe_and_tangent(xs, dg.to(dt), cfg.multires)
     # the kernel evaluates the tangent / adjoint columns for K (du, dg), K a power of two that brings them into fp16's range; emulated by
@@ -66,7 +67,7 @@ def sweep(state, cfg, x, du, dg, passes):
         out[l] = (torch.cat([zb / k_t, zbp], 0).t().contiguous().double(), torch.cat([a, ap / k_t], 0).t().contiguous().double())
         if l == 0:
             break
-        ab, abp = mm(Ws[l].t(), zb), mm(Ws[l].t(), zbp)
+        ab, abp = mmb(Ws[l].t(), zb), mmb(Ws[l].t(), zbp)
         if l in cfg.skip_in:
             n_prev = Ws[l].shape[1] - pe.shape[1]
             ab, abp = ab[:, :n_prev] / np.sqrt(2), abp[:, :n_prev] / np.sqrt(2)
@@ -88,8 +89,14 @@ def main():
     x = (torch.rand(a.points, 3) * 2.4 - 1.2)
     du, dg = torch.randn(a.points) * 1e-3, torch.randn(a.points, 3) * 1e-4
     ref = {l: Z @ A.t() for l, (Z, A) in sweep(st64, cfg, x.double(), du.double(), dg.double(), None).items()}
-    for name, passes in (("f16 cross terms (shipped)", "hh+hl+lh"), ("MX e2m3 cross terms, forward and backward GEMMs", "k6:rne"), ("no cross terms at all (hi x hi)", "hh")):
-        ops = sweep(st32, cfg, x, du, dg, passes)
+    f3 = "hh+hl+lh"
+    for name, passes, pb in (("f16 cross terms (shipped)", f3, None), ("MX e2m3 cross terms, forward and backward GEMMs", "k6:rne", None),
+                             ("forward f16 x 3, backward GEMMs MX e2m3 cross terms", f3, "k6:rne"), ("forward f16 x 3, backward GEMMs hi x hi only", f3, "hh"),
+                             ("forward f16 x 3, backward GEMMs without the weights' lo parts", f3, "hh+hl"),
+                             ("forward f16 x 3, backward GEMMs without the deltas' lo parts", f3, "hh+lh"),
+                             ("only W_hi x_lo everywhere (the weights' lo parts dropped)", "hh+hl", None), ("only W_lo x_hi everywhere (the activations' lo parts dropped)", "hh+lh", None),
+                             ("no cross terms at all (hi x hi)", "hh", None)):
+        ops = sweep(st32, cfg, x, du, dg, passes, pb)
         e_exact = max(float(((Z @ A.t()) - ref[l]).abs().max() / ref[l].abs().max()) for l, (Z, A) in ops.items())
         e_wgrad = max(float(((WG.hi16(Z) @ WG.hi16(A).t()) - ref[l]).abs().max() / ref[l].abs().max()) for l, (Z, A) in ops.items())
         print(json.dumps({"sweep GEMMs": name, "points": a.points, "dW from the sweep's operands in fp64: worst layer": float(f"{e_exact:.3e}"),
