@@ -223,3 +223,14 @@ def test_default_bench_line_carries_the_training_step():
     tr = line["train"]
     assert "error" not in tr and tr["ms_per_step"] > 0 and 0 < tr["whole_step_frac"] < 1 and tr["value"] > 0
     assert line["config"]["settle_steps"] == 3 and line["roofline"]["kernel"].startswith("udf_mlp_rev32_kernel")
+
+
+def test_dry_run_nccl_self_check_reports():
+    """`python bench.py --dry-run-nccl`: on a box with >= 2 GPUs it constructs the nccl group and steps eagerly and from per-phase graphs; with one GPU
+    it says so and exits 0 (never a traceback): the first multi-GPU lease starts from a known state."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run-nccl"], capture_output=True, text=True, timeout=1500)
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    if torch.cuda.device_count() < 2:
+        assert out.returncode == 0 and line["dry_run_nccl"] == "skipped"
+    else:
+        assert out.returncode == 0 and line["dry_run_nccl"] == "ok", (line, out.stderr[-2000:])
