@@ -85,6 +85,7 @@ SYMBOLS = {
     "emap_embed": (C.c_int, [_P, C.c_int64, C.c_int, _P, _P]),
     "emap_null_direction": (C.c_int, [_P, C.c_int64, C.c_int, _P, _P]),
     "emap_sample_pdf": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
+    "emap_sample_pdf_u": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
     "emap_upsample_step": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_float, C.c_float, C.c_float,
                                      _P, _P, _P, _P]),
     "emap_merge_sorted": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),

@@ -44,7 +44,7 @@ struct ProfScope {   // records a HIP event pair around one launch on its stream
     ~ProfScope() { if (on) { (void)hipEventRecord(g_prof_ev[k][g_prof_n[k]][1], st); ++g_prof_n[k]; } }
 };
 
-int launch_sample_pdf(const float*, const float*, int, int, int, float*, int64_t*, int32_t*, hipStream_t);
+int launch_sample_pdf(const float*, const float*, int, int, int, float*, int64_t*, int32_t*, hipStream_t, const float* u = nullptr);
 int launch_upsample(const float*, const float*, const float*, const float*, int, int, int, const float*, float, float,
                     float, float*, int64_t*, int32_t*, hipStream_t);
 int launch_merge(const float*, const float*, const float*, const float*, int, int, int, float*, float*, int64_t*,
@@ -277,6 +277,11 @@ int emap_sample_pdf(const float* bins, const float* weights, int N, int n, int m
                     int32_t* err_flags, void* stream) {
     if (N > 0 && (!bins || !weights || !samples)) { set_error("sample_pdf: null pointer"); return EMAP_E_INVALID; }
     return launch_sample_pdf(bins, weights, N, n, m, samples, inds, err_flags, static_cast<hipStream_t>(stream));
+}
+int emap_sample_pdf_u(const float* bins, const float* weights, const float* u, int N, int n, int m, float* samples, int64_t* inds,
+                      int32_t* err_flags, void* stream) {
+    if (N > 0 && (!bins || !weights || !samples || !u)) { set_error("sample_pdf_u: null pointer"); return EMAP_E_INVALID; }
+    return launch_sample_pdf(bins, weights, N, n, m, samples, inds, err_flags, static_cast<hipStream_t>(stream), u);
 }
 
 int emap_upsample_step(const float* rays_o, const float* rays_d, const float* z, const float* udf, int N, int n, int m,

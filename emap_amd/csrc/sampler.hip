@@ -113,8 +113,9 @@ __device__ __forceinline__ float udf2logistic1(float udf, float inv_s) {
 // ---------------------------------------------------------------------------------------------
 // sample_pdf on LDS data (bins[n], w[n-1] raw weights; scratch pdf[n], cdf[n])
 // ---------------------------------------------------------------------------------------------
+// u_in (optional, m values of this ray): the caller's uniform draws - sample_pdf(det=False), :84-85 - instead of the deterministic grid
 __device__ __forceinline__ void sample_pdf_wave(const float* bins, const float* w, float* pdf, float* cdf, int n, int m,
-                                                int lane, float* samples_out, int64_t* inds_out, int32_t* err) {
+                                                int lane, float* samples_out, int64_t* inds_out, int32_t* err, const float* u_in = nullptr) {
     const int nw = n - 1;
     double part = 0.0;
     for (int e = lane; e < nw; e += 64) {
@@ -129,7 +130,7 @@ __device__ __forceinline__ void sample_pdf_wave(const float* bins, const float* 
     const float u0 = (float)(0.0 + 0.5 / (double)m), u1 = (float)(1.0 - 0.5 / (double)m);
     bool nan = false;
     for (int k = lane; k < m; k += 64) {
-        const float u = linspace_at(u0, u1, m, k);
+        const float u = u_in ? u_in[k] : linspace_at(u0, u1, m, k);
         // searchsorted(cdf, u, right=True): first index with cdf[idx] > u
         int lo = 0, hi = n;
         while (lo < hi) {
@@ -151,13 +152,14 @@ __device__ __forceinline__ void sample_pdf_wave(const float* bins, const float* 
 }
 
 __global__ __launch_bounds__(64) void sample_pdf_kernel(const float* bins, const float* weights, int N, int n, int m,
-                                                        float* samples, int64_t* inds, int32_t* err) {
+                                                        float* samples, int64_t* inds, int32_t* err, const float* u) {
     __shared__ float s_bins[MAXS], s_w[MAXS], s_pdf[MAXS], s_cdf[MAXS + 1];
     const int ray = blockIdx.x, lane = threadIdx.x;
     for (int e = lane; e < n; e += 64) s_bins[e] = bins[(size_t)ray * n + e];
     for (int e = lane; e < n - 1; e += 64) s_w[e] = weights[(size_t)ray * (n - 1) + e];
     __syncthreads();
-    sample_pdf_wave(s_bins, s_w, s_pdf, s_cdf, n, m, lane, samples + (size_t)ray * m, inds ? inds + (size_t)ray * m : nullptr, err);
+    sample_pdf_wave(s_bins, s_w, s_pdf, s_cdf, n, m, lane, samples + (size_t)ray * m, inds ? inds + (size_t)ray * m : nullptr, err,
+                    u ? u + (size_t)ray * m : nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -789,10 +791,10 @@ __global__ __launch_bounds__(256) void embed_kernel(const float* x, long long P,
 // launchers
 // ---------------------------------------------------------------------------------------------
 int launch_sample_pdf(const float* bins, const float* weights, int N, int n, int m, float* samples, int64_t* inds,
-                      int32_t* err, hipStream_t st) {
+                      int32_t* err, hipStream_t st, const float* u) {
     if (n < 2 || n > MAXS || m < 1 || m > MAXS) { set_error("sample_pdf: n=%d m=%d out of range (max %d)", n, m, MAXS); return EMAP_E_INVALID; }
     if (N <= 0) return EMAP_OK;
-    hipLaunchKernelGGL(sample_pdf_kernel, dim3(N), dim3(64), 0, st, bins, weights, N, n, m, samples, inds, err);
+    hipLaunchKernelGGL(sample_pdf_kernel, dim3(N), dim3(64), 0, st, bins, weights, N, n, m, samples, inds, err, u);
     return check_launch("sample_pdf");
 }
 

@@ -22,16 +22,20 @@ _PER_SAMPLE = ("weights", "alpha", "mid_z", "dists", "inside_sphere", "gradient_
 
 
 def sample_pdf(bins, weights, n_samples, det=False):
-    """reference udf_renderer_blending.py:69-109 (deterministic u only - the hot path calls det=True)."""
-    if not det:
-        raise NotImplementedError("sample_pdf(det=False) is not on the EMAP render path")
+    """reference udf_renderer_blending.py:69-109.  det=True (what the render path calls): the deterministic u grid; det=False: u drawn as
+    the reference draws it - torch.rand(N, n_samples) on the CPU generator, then moved to the device (:84-85)."""
     _lib.require_cuda(bins, "bins")
     b, w = _lib.f32c(bins), _lib.f32c(weights)
     N, n = b.shape
     out = torch.empty(N, n_samples, device=b.device, dtype=torch.float32)
     with _lib.on_device(b):
-        _lib.check(_lib.lib().emap_sample_pdf(_lib.ptr(b), _lib.ptr(w), N, n, n_samples, _lib.ptr(out), None, None,
-                                              _lib.stream_ptr(b.device)), "sample_pdf")
+        if det:
+            _lib.check(_lib.lib().emap_sample_pdf(_lib.ptr(b), _lib.ptr(w), N, n, n_samples, _lib.ptr(out), None, None,
+                                                  _lib.stream_ptr(b.device)), "sample_pdf")
+        else:
+            u = torch.rand([N, n_samples]).to(b.device).contiguous()
+            _lib.check(_lib.lib().emap_sample_pdf_u(_lib.ptr(b), _lib.ptr(w), _lib.ptr(u), N, n, n_samples, _lib.ptr(out), None, None,
+                                                    _lib.stream_ptr(b.device)), "sample_pdf_u")
     return out
 
 

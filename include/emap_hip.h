@@ -109,6 +109,10 @@ int emap_embed(const float* x, int64_t P, int multires, float* pe, void* stream)
  *                      perm int64 (N,n+m) (may be NULL); udf/udf_new/udf_out may be NULL (last=True) */
 int emap_sample_pdf(const float* bins, const float* weights, int N, int n, int m, float* samples,
                     int64_t* inds, int32_t* err_flags, void* stream);
+/* emap_sample_pdf_u : the same with the caller's uniform draws u (N, m) instead of the deterministic grid: sample_pdf(det=False)
+ *                      (udf_renderer_blending.py:84-85; the reference draws u with torch.rand on the CPU generator) */
+int emap_sample_pdf_u(const float* bins, const float* weights, const float* u, int N, int n, int m, float* samples, int64_t* inds,
+                      int32_t* err_flags, void* stream);
 int emap_upsample_step(const float* rays_o, const float* rays_d, const float* z, const float* udf, int N, int n,
                        int m, const float* sample_dist_dev, float inv_s, float beta, float gamma, float* z_new,
                        int64_t* inds, int32_t* err_flags, void* stream);

@@ -142,6 +142,27 @@ def g3_sample_pdf():
     save("g3_sample_pdf", **out)
 
 
+def g13_sample_pdf_random():
+    """sample_pdf(det=False) (udf_renderer_blending.py:84-85): u = torch.rand on the CPU generator; seed, draws and samples recorded"""
+    rng = np.random.Generator(np.random.PCG64(113))
+    N, n = 24, 48
+    bins_t = torch.tensor(np.sort(rng.uniform(0.05, 6.0, size=(N, n)), axis=-1), dtype=torch.float32)
+    w = rng.uniform(0, 1, size=(N, n - 1)) ** 4
+    w[:3] = 0.0
+    w[3:6, 8:] = 0.0
+    w_t = torch.tensor(w, dtype=torch.float32)
+    out = {"bins": bins_t, "weights": w_t, "seed": np.int64(20240613)}
+    for m in (7, 32):
+        torch.manual_seed(20240613 + m)
+        with capture("searchsorted") as rec:
+            s = sample_pdf(bins_t, w_t, m, det=False)
+        torch.manual_seed(20240613 + m)
+        out[f"u_m{m}"] = torch.rand([N, m])
+        out[f"samples_m{m}"] = s
+        out[f"inds_m{m}"] = rec[0]
+    save("g13_sample_pdf_random", **out)
+
+
 def make_renderer(net, n_samples, n_importance, steps, variance=0.3, beta=0.5, gamma=0.3, perturb=1.0):
     dev = SingleVarianceNetwork(variance)
     bet = BetaNetwork(init_var_beta=beta, init_var_gamma=gamma, init_var_zeta=0.3, beta_min=0.00005,
@@ -483,6 +504,6 @@ def g11_rays():
 if __name__ == "__main__":
     only = sys.argv[1:]
     for fn in (g1_pe, g2_mlp, g3_sample_pdf, g4_upsample_step, g5_render, g6_training, g7_perturb, g8_scalars, g9_seeded_init,
-               g10_extraction, g11_rays, g12_training_steps):
+               g10_extraction, g11_rays, g12_training_steps, g13_sample_pdf_random):
         if not only or fn.__name__ in only:
             fn()

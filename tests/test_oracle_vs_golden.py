@@ -69,6 +69,18 @@ def test_g3_sample_pdf_indices_bit_exact(m):
     assert torch.equal(s, t(g[f"samples_m{m}"]))
 
 
+@pytest.mark.parametrize("m", [7, 32])
+def test_g13_sample_pdf_with_random_draws_bit_exact(m):
+    """sample_pdf(det=False): the reference's torch.rand draws are reproducible from the recorded seed, and the oracle inverts the CDF on them bit for bit"""
+    g = load_golden("g13_sample_pdf_random")
+    torch.manual_seed(int(g["seed"]) + m)
+    u = torch.rand([g["bins"].shape[0], m])
+    assert torch.equal(u, t(g[f"u_m{m}"]))
+    s, inds = O.sample_pdf(t(g["bins"]), t(g["weights"]), m, det=False, return_inds=True, u=u)
+    assert torch.equal(inds, t(g[f"inds_m{m}"]))
+    assert torch.equal(s, t(g[f"samples_m{m}"]))
+
+
 def test_g4_upsample_and_merge():
     g = load_golden("g4_upsample_step")
     _, state = net_state("d8w256L10")
