@@ -28,11 +28,37 @@ __device__ __forceinline__ float sigmoidf_(float x) { return FDIV(1.0f, FADD(1.0
 __device__ __forceinline__ float clipf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 __device__ __forceinline__ float relu_(float x) { return fmaxf(x, 0.0f); }
 
-__device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+// Cross-lane fp64 scans on the DPP network instead of ds_bpermute shuffles (round 4: a __shfl_up / __shfl_xor of a double is two LDS-crossbar
+// round trips of ~130 cycles, six steps per scan, three scans and a sum per importance-sampling step: profiles/r04_sampler_timeline_*.txt).
+// dpp_d: both halves of a double through v_mov_b32_dpp with the same control; lanes without a source keep `ident`.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_d(double ident, double v) {
+    const unsigned long long iv = __builtin_bit_cast(unsigned long long, ident), sv = __builtin_bit_cast(unsigned long long, v);
+    const int lo = __builtin_amdgcn_update_dpp((int)(unsigned)iv, (int)(unsigned)sv, CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(unsigned)(iv >> 32), (int)(unsigned)(sv >> 32), CTRL, ROW_MASK, 0xf, false);
+    return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo);
+}
+// inclusive scan over the 64 lanes: row_shr 1, 2, 4, 8 inside the rows of 16, then row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3
+// (the gfx9 wave64 sequence); lane 63 ends with the total
+template <bool MUL>
+__device__ __forceinline__ double wave_scan_incl_d(double v) {
+    const double id = MUL ? 1.0 : 0.0;
+#define EMAP_SCAN_STEP(CTRL, RM) { const double o_ = dpp_d<CTRL, RM>(id, v); v = MUL ? v * o_ : v + o_; }
+    EMAP_SCAN_STEP(0x111, 0xf)   // row_shr:1
+    EMAP_SCAN_STEP(0x112, 0xf)   // row_shr:2
+    EMAP_SCAN_STEP(0x114, 0xf)   // row_shr:4
+    EMAP_SCAN_STEP(0x118, 0xf)   // row_shr:8
+    EMAP_SCAN_STEP(0x142, 0xa)   // row_bcast:15 -> rows 1, 3
+    EMAP_SCAN_STEP(0x143, 0xc)   // row_bcast:31 -> rows 2, 3
+#undef EMAP_SCAN_STEP
     return v;
 }
+__device__ __forceinline__ double readlane63_d(double v) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), 63);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double wave_sum_d(double v) { return readlane63_d(wave_scan_incl_d<false>(v)); }
 
 // Exclusive prefix product (MUL=true) or inclusive prefix sum (MUL=false) over n <= MAXS values in
 // LDS, fp64 accumulation, fp32 outputs.  Each lane owns a contiguous chunk of C = ceil(n/64) values.
@@ -47,15 +73,9 @@ __device__ __forceinline__ void wave_scan(const float* in, float* out, int n, in
         const int e = b + i;
         if (e < n) loc = MUL ? loc * (double)in[e] : loc + (double)in[e];
     }
-    // exclusive scan of the chunk totals across lanes (Kogge-Stone)
-    double inc = loc;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const double o = __shfl_up(inc, off);
-        if (lane >= off) inc = MUL ? inc * o : inc + o;
-    }
-    double pre = __shfl_up(inc, 1);
-    if (lane == 0) pre = MUL ? 1.0 : 0.0;
+    // exclusive scan of the chunk totals across lanes: inclusive scan on the DPP network, shifted by one lane (wave_shr:1, lane 0 keeps the identity)
+    const double inc = wave_scan_incl_d<MUL>(loc);
+    const double pre = dpp_d<0x138, 0xf>(MUL ? 1.0 : 0.0, inc);
     double run = pre;
     for (int i = 0; i < C; ++i) {
         const int e = b + i;
