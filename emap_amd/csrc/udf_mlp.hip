@@ -414,7 +414,7 @@ int build_layout(const EmapNetConfig* cfg, int prec, NetLayout* L) {
     if (!cfg || !L) { set_error("null config"); return EMAP_E_INVALID; }
     if (cfg->d_hidden != 256 && cfg->d_hidden != 128) { set_error("d_hidden must be 128 or 256 (got %d)", cfg->d_hidden); return EMAP_E_INVALID; }
     if (cfg->n_lin < 2 || cfg->n_lin > EMAP_MAX_LIN) { set_error("n_lin out of range (%d)", cfg->n_lin); return EMAP_E_INVALID; }
-    if (cfg->multires < 1 || cfg->multires > 10) { set_error("multires must be in 1..10 (got %d)", cfg->multires); return EMAP_E_INVALID; }
+    if (cfg->multires < 0 || cfg->multires > 10) { set_error("multires must be in 0..10 (got %d)", cfg->multires); return EMAP_E_INVALID; }   // 0: raw coordinates only (udf_model.py:26-29)
     if (cfg->d_out != 1) { set_error("d_out must be 1 (got %d): feature outputs are not on the hot path", cfg->d_out); return EMAP_E_INVALID; }
     if (prec < EMAP_PREC_BF16 || prec > EMAP_PREC_F16X3M) { set_error("unknown precision mode %d", prec); return EMAP_E_INVALID; }
     if (prec == EMAP_PREC_F16X3M && (cfg->d_hidden != 256 || !EMAP_REV_MX6)) {

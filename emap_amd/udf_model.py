@@ -100,8 +100,8 @@ class UDFNetwork(nn.Module):
         return gs, vs, bs
 
     def net_config(self) -> _lib.NetConfig:
-        if self.d_in != 3 or self.multires <= 0:
-            raise NotImplementedError("the HIP UDF MLP needs d_in=3 and multires>0 (all EMAP configs)")
+        if self.d_in != 3 or self.multires < 0:
+            raise NotImplementedError("the HIP UDF MLP needs d_in=3 (all EMAP configs)")
         if self.d_out != 1:
             raise NotImplementedError("the HIP UDF MLP supports d_out=1 (all EMAP configs); feature outputs are unused")
         skips = [s for s in self.skip_in if 0 < s < self.num_layers - 1]
@@ -201,7 +201,8 @@ class UDFNetwork(nn.Module):
             udf, _ = UdfFn.apply(self, inputs, False, *self.parameters())
         else:
             udf, _ = self.hip_udf(inputs)
-        pe = self.embed_fn_fine(inputs.detach() * self.scale)
+        xs = inputs.detach() * self.scale
+        pe = self.embed_fn_fine(xs) if self.embed_fn_fine is not None else xs       # multires = 0: no embedding (udf_model.py:92-93)
         return udf, pe
 
     def udf(self, x):

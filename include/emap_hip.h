@@ -62,7 +62,7 @@ typedef struct EmapNetConfig {
     int32_t d_hidden;   /* 128 or 256                                   */
     int32_t n_lin;      /* number of Linear layers = n_layers + 1       */
     int32_t skip_l;     /* layer whose input is cat([x, PE])/sqrt2, or -1 (skip_in=(4,) -> 4) */
-    int32_t multires;   /* 1..10 positional-encoding octaves            */
+    int32_t multires;   /* 0..10 positional-encoding octaves (0: raw xyz) */
     int32_t d_out;      /* must be 1                                    */
     int32_t udf_type;   /* EMAP_UDF_*                                   */
     float scale;        /* inputs * scale, udf / scale (udf_model.py:91,108) */

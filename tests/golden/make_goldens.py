@@ -142,6 +142,25 @@ def g3_sample_pdf():
     save("g3_sample_pdf", **out)
 
 
+def g14_mlp_multires0():
+    """multires = 0 (udf_model.py:26-29: no embedding, dims[0] = 3; the geometric initialisation takes its plain branch): value, "PE" (= the scaled
+    input) and gradient of the reference network, d8 w256 and d4 w128"""
+    rng = np.random.Generator(np.random.PCG64(114))
+    x = torch.tensor(rng.uniform(-1.2, 1.2, size=(256, 3)), dtype=torch.float32)
+    out = {"x": x}
+    for name, kw, seed in (("d8w256L0", dict(d_in=3, d_out=1, d_hidden=256, n_layers=8, skip_in=(4,), multires=0, bias=0.5), 46),
+                           ("d4w128L0", dict(d_in=3, d_out=1, d_hidden=128, n_layers=4, skip_in=(4,), multires=0, bias=0.5), 47)):
+        net = UDFNetwork(scale=1.0, geometric_init=True, weight_norm=True, udf_type="abs", **kw)
+        state = synthetic.make_udf_state(seed=seed, pert=0.02, **kw)
+        net.load_state_dict(state)
+        fo, pe = net(x)
+        out[f"{name}.out"] = fo.detach()
+        out[f"{name}.pe"] = pe.detach()
+        out[f"{name}.grad"] = net.gradient(x.clone()).detach()
+        out[f"{name}.wsum"] = state_checksum(state)
+    save("g14_mlp_multires0", **out)
+
+
 def g13_sample_pdf_random():
     """sample_pdf(det=False) (udf_renderer_blending.py:84-85): u = torch.rand on the CPU generator; seed, draws and samples recorded"""
     rng = np.random.Generator(np.random.PCG64(113))
@@ -504,6 +523,6 @@ def g11_rays():
 if __name__ == "__main__":
     only = sys.argv[1:]
     for fn in (g1_pe, g2_mlp, g3_sample_pdf, g4_upsample_step, g5_render, g6_training, g7_perturb, g8_scalars, g9_seeded_init,
-               g10_extraction, g11_rays, g12_training_steps, g13_sample_pdf_random):
+               g10_extraction, g11_rays, g12_training_steps, g13_sample_pdf_random, g14_mlp_multires0):
         if not only or fn.__name__ in only:
             fn()

@@ -371,3 +371,41 @@ def test_jitter_draw_is_the_reference_cpu_draw():
     got = [r._jitter_draw(40, torch.device(DEV)).cpu().reshape(40, 1) for _ in range(7)]
     for a_, b_ in zip(ref, got):
         assert torch.equal(a_, b_)
+
+
+@pytest.mark.parametrize("name,H,nl,seed", [("d8w256L0", 256, 8, 46), ("d4w128L0", 128, 4, 47)])
+def test_network_without_positional_encoding_vs_reference_golden(name, H, nl, seed):
+    """multires = 0 (udf_model.py:26-29: raw coordinates, dims[0] = 3): value, "PE" and gradient against the reference's recording (g14) through every MLP
+    kernel (small launch: fs2 value / forward-mode gradient; large launch: reverse sweep), and the training gradients against autograd through the oracle."""
+    from oracle import emap_oracle as O
+    g = load_golden("g14_mlp_multires0")
+    kw = dict(d_in=3, d_out=1, d_hidden=H, n_layers=nl, skip_in=(4,), multires=0, bias=0.5)
+    state = synthetic.make_udf_state(seed=seed, pert=0.02, **kw)
+    net = emap_amd.UDFNetwork(scale=1.0, precision="f16x3", **kw)
+    net.load_state_dict(state)
+    net = net.to(DEV)
+    x = torch.from_numpy(g["x"]).to(DEV)
+    ur, gr = torch.from_numpy(g[f"{name}.out"])[:, :1], torch.from_numpy(g[f"{name}.grad"]).reshape(-1, 3)
+    with torch.no_grad():
+        out, pe = net(x)
+        u, gd = net.hip_udf(x, with_grad=True)
+        xb = torch.cat([x, (torch.rand(70000, 3, generator=torch.Generator().manual_seed(1)) * 2.4 - 1.2).to(DEV)])
+        ub, gb = net.hip_udf(xb, with_grad=True)
+    assert torch.equal(pe.cpu(), torch.from_numpy(g[f"{name}.pe"]))
+    assert rel(out, ur) <= 1e-4 and rel(u, ur) <= 1e-4 and rel(gd, gr) <= 1e-4
+    assert rel(ub[:256], ur) <= 1e-4 and rel(gb[:256], gr) <= 1e-4
+    # training: d/dtheta of sum(udf^2) + sum(grad^2) through the HIP backward vs autograd through the oracle (fp64)
+    xs = (torch.rand(2048, 3, generator=torch.Generator().manual_seed(2)) * 2 - 1)
+    xg = xs.to(DEV).requires_grad_(True)
+    o, _ = net(xg)
+    loss = (o ** 2).sum() + (net.gradient(xg) ** 2).sum()
+    loss.backward()
+    st64 = {k: v.double().requires_grad_(True) for k, v in state.items()}
+    cfg = O.UDFConfig(d_hidden=H, n_layers=nl, multires=0)
+    uo, go = O.udf_value_and_grad(st64, cfg, xs.double())       # plain torch ops: differentiable w.r.t. the state
+    lo = (uo ** 2).sum() + (go ** 2).sum()
+    grads = torch.autograd.grad(lo, list(st64.values()))
+    assert float(loss) == pytest.approx(float(lo), rel=2e-4)
+    params = dict(net.named_parameters())
+    for (k, _), gref in zip(st64.items(), grads):
+        assert rel(params[k].grad, gref) <= 1e-3, k

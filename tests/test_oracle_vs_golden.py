@@ -69,6 +69,20 @@ def test_g3_sample_pdf_indices_bit_exact(m):
     assert torch.equal(s, t(g[f"samples_m{m}"]))
 
 
+@pytest.mark.parametrize("name,H,nl,seed", [("d8w256L0", 256, 8, 46), ("d4w128L0", 128, 4, 47)])
+def test_g14_mlp_without_positional_encoding(name, H, nl, seed):
+    """multires = 0 (udf_model.py:26-29): the oracle on the recorded network equals the reference's value / gradient"""
+    from emap_amd import synthetic
+    g = load_golden("g14_mlp_multires0")
+    kw = dict(d_in=3, d_out=1, d_hidden=H, n_layers=nl, skip_in=(4,), multires=0, bias=0.5)
+    state = synthetic.make_udf_state(seed=seed, pert=0.02, **kw)
+    cfg = O.UDFConfig(d_hidden=H, n_layers=nl, multires=0)
+    u, gr = O.udf_value_and_grad(state, cfg, t(g["x"]))
+    assert float((u - t(g[f"{name}.out"])[:, :1]).abs().max()) <= 2e-5 * float(t(g[f"{name}.out"]).abs().max())
+    ref = t(g[f"{name}.grad"]).reshape(-1, 3)
+    assert float((gr - ref).abs().max()) <= 2e-4 * float(ref.abs().max())
+
+
 @pytest.mark.parametrize("m", [7, 32])
 def test_g13_sample_pdf_with_random_draws_bit_exact(m):
     """sample_pdf(det=False): the reference's torch.rand draws are reproducible from the recorded seed, and the oracle inverts the CDF on them bit for bit"""
