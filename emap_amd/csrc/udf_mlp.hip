@@ -2,6 +2,7 @@
 // fused UDF-MLP kernels.  The kernels themselves live in udf_mlp_kernel.inc, instantiated per precision mode in
 // udf_mlp_{bf16,bf16x3,f16,f16x3}.hip.
 #include "emap_common.h"
+#include <atomic>
 #include <stdlib.h>
 #include <string.h>
 
@@ -525,17 +526,13 @@ static int grad_mode_from_env() {
     const char* gm = getenv("EMAP_GRAD_MODE");
     return !gm ? -1 : (!strcmp(gm, "fwd") ? 0 : (!strcmp(gm, "rev") ? 1 : -1));
 }
-static int g_grad_mode = grad_mode_from_env();
-int set_grad_mode(int mode) {
-    const int old = g_grad_mode;
-    g_grad_mode = (mode == 0 || mode == 1) ? mode : -1;
-    return old;
-}
+static std::atomic<int> g_grad_mode{grad_mode_from_env()};   // process-wide; atomic: callers on several threads / devices read it per launch
+int set_grad_mode(int mode) { return g_grad_mode.exchange((mode == 0 || mode == 1) ? mode : -1, std::memory_order_relaxed); }
 static int mlp_variant(const NetLayout& L, int prec, int64_t P, bool grad) {
     // reverse mode halves the MFMA work of a grad launch but a tile is two dependent sweeps: it wins once most CUs have a
     // workgroup (measured crossover: the split modes between 8k and 12k points, single-pass modes at 16k).
     const int64_t rev_min = (prec == EMAP_PREC_F16X3 || prec == EMAP_PREC_F16X3M || prec == EMAP_PREC_BF16X3) ? 10240 : 16384;
-    const int gm = g_grad_mode;
+    const int gm = g_grad_mode.load(std::memory_order_relaxed);
     if (grad && L.has_rev && gm != 0 && (P >= rev_min || gm == 1)) return 3;
     return 2;
 }

@@ -100,7 +100,9 @@ class Trainer:
                  igr_ns_weight: float = 0.0, group=None, eikonal_sync: str = "exact", fused_adam: Optional[bool] = None,
                  native_tail: Optional[bool] = None):
         assert eikonal_sync in ("exact", "exact_lagged", "local")
-        assert _world(group) <= self.MAX_RANKS
+        # only "exact_lagged" uses the rank-indexed maxima slots of the bucket's tail: "exact" / "local" run on any number of ranks
+        assert eikonal_sync != "exact_lagged" or _world(group) <= self.MAX_RANKS, \
+            f"eikonal_sync='exact_lagged' keeps two range maxima per rank in the gradient bucket's tail: at most {self.MAX_RANKS} ranks"
         self.r = renderer
         self.group = group
         self.eikonal_sync = eikonal_sync
@@ -108,7 +110,8 @@ class Trainer:
         net = renderer.udf_network
         self.geo = list(net.parameters())
         self.scalars = [renderer.deviation_network.variance, renderer.beta_network.beta, renderer.beta_network.gamma]
-        self.flat = FlatParams(self.geo + self.scalars, extra=self.N_STATS + 2 * self.MAX_RANKS)
+        # tail of the bucket: the step statistics; "exact_lagged" only: + two range maxima per rank
+        self.flat = FlatParams(self.geo + self.scalars, extra=self.N_STATS + (2 * self.MAX_RANKS if eikonal_sync == "exact_lagged" else 0))
         renderer._lay = None                      # the layout caches tensor identities / pointers: rebuild on the flat views
         lay = renderer._layout()
         assert lay.numel == self.flat.numel and all(lay.offsets[id(p)] == self.flat.offsets[id(p)] for p in self.flat.params)
@@ -478,6 +481,56 @@ class FusedAdam(torch.optim.Optimizer):
         self._tail_step = torch.zeros(max(n - self._n_geo, 1), device=dev)
         self._flags = None
         self._zeros = {}
+
+    # ---- checkpointing (runner_udf.py:260 saves optimizer.state_dict(), :273 loads it): torch.optim.Adam's per-parameter layout ----
+    def _span(self, p):
+        o = self._flat.offsets[id(p)]
+        return o, o + p.numel()
+
+    def _mirror_state(self):
+        """Expose the flat moments as ``self.state[p] = {step, exp_avg, exp_avg_sq}`` (views of the flat buffers, torch.optim.Adam's
+        keys), so that ``Optimizer.state_dict()`` writes a checkpoint a stock Adam can load and vice versa.  A parameter that has
+        never been stepped (frozen so far) has no entry, exactly like torch's Adam.  Reads the step counters: a host sync."""
+        t_geo = float(self._t.item())
+        tail_steps = self._tail_step.tolist()
+        self.state.clear()
+        for p in self._geo + self._tail:
+            a, b = self._span(p)
+            step = t_geo if a < self._n_geo else float(tail_steps[a - self._n_geo])
+            if step <= 0:
+                continue
+            self.state[p] = {"step": torch.tensor(step, dtype=torch.float32), "exp_avg": self._m[a:b].view(p.shape),
+                             "exp_avg_sq": self._v[a:b].view(p.shape)}
+
+    def state_dict(self):
+        if self._flat is not None:
+            self._mirror_state()
+        return super().state_dict()
+
+    @torch.no_grad()
+    def load_state_dict(self, state_dict):
+        """Accepts a checkpoint of this class or of ``torch.optim.Adam`` over the same parameter groups: moments and step counts go into
+        the flat buffers (the geometry range has ONE step counter - its parameters always step together; every tail element its own)."""
+        super().load_state_dict(state_dict)           # validates the groups, casts the tensors to the parameters' device
+        if self._flat is None:
+            self._build()
+        self._m.zero_(); self._v.zero_(); self._t.zero_(); self._tail_step.zero_()
+        t_geo = 0.0
+        for p in self._geo + self._tail:
+            st = self.state.get(p)
+            if not st:
+                continue
+            a, b = self._span(p)
+            self._m[a:b].copy_(st["exp_avg"].reshape(-1))
+            self._v[a:b].copy_(st["exp_avg_sq"].reshape(-1))
+            step = float(st["step"])
+            if a < self._n_geo:
+                t_geo = max(t_geo, step)
+            else:
+                self._tail_step[a - self._n_geo:b - self._n_geo] = step
+        self._t.fill_(t_geo)
+        self._flags = None
+        self._mirror_state()
 
     @torch.no_grad()
     def step(self, closure=None):

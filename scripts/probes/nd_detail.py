@@ -6,14 +6,15 @@ import torch
 from test_gpu_parity import mk
 prec = sys.argv[1] if len(sys.argv) > 1 else "bf16x3"
 P = int(sys.argv[2]) if len(sys.argv) > 2 else 131072
-os.environ["EMAP_GRAD_MODE"] = "rev"
+from emap_amd import _lib
+_lib.lib().emap_set_grad_mode(1)   # reverse sweep regardless of size (the environment variable is read once, at load)
 net, state, cfg = mk("d8w256L10", prec)
 gen = torch.Generator().manual_seed(5)
 x = (torch.rand(P, 3, generator=gen) * 2 - 1).cuda()
 outs = []
 for i in range(4):
     u, g = net.hip_udf(x, with_grad=True); torch.cuda.synchronize(); outs.append((u.clone().cpu(), g.clone().cpu()))
-os.environ["EMAP_GRAD_MODE"] = "fwd"
+_lib.lib().emap_set_grad_mode(0)   # forward-mode tangents
 uf, gf = net.hip_udf(x, with_grad=True); uf, gf = uf.cpu(), gf.cpu()
 e_all = (outs[0][1] - gf).abs().max(dim=1).values
 print(f"run 0 vs forward-mode kernel: max |dgrad| {float(e_all.max()):.3e}, rel to max {float(e_all.max() / gf.abs().max()):.2e}; udf max diff {float((outs[0][0] - uf).abs().max()):.2e}")
