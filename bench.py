@@ -62,7 +62,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--mode", default="render", choices=["render", "train"])
-    ap.add_argument("--path", default="native", choices=["native", "dropin", "dropin-fused"],
+    ap.add_argument("--path", default="native", choices=["native", "dropin", "dropin-fused", "dropin-patched"],
                     help="train mode, one GPU: native = emap_amd.parallel.Trainer (flat buffers, fused Adam); dropin = the reference runner's own "
                          "step on the drop-in classes (autograd, torch.optim.Adam, .item() reads); dropin-fused = the same with emap_amd's FusedAdam")
     ap.add_argument("--rays", type=int, default=512, help="rays per GPU (weak scaling)")
@@ -214,80 +214,145 @@ def _timed(fn, steps, warmup):
     return dt, sorted(s_ev.elapsed_time(e_ev) for s_ev, e_ev in evs)[steps // 2]
 
 
-def train_dropin_key(dev, precision, rays, steps=40, warmup=10, n_samples=64, n_importance=64, up_sample_steps=4, fused_adam=False):
-    """The optimizer step AS THE REFERENCE'S RUNNER TAKES IT (src/runner/runner_udf.py:63-168 with runner_base.py:96-126) on the
-    classes `emap_amd.dropin.install()` puts under `src.models.*`: the dataset's ray draw (the device sampler the drop-in patches
-    in), `renderer.render()` under autograd (RenderFn), EdgeLoss, the runner's loss assembly with its host reads
-    (`beta.item()`, `loss.item()`), `loss.backward()`, `torch.optim.Adam` over the runner's parameter groups (27 + 5 tensors).
-    The runner module itself needs pyhocon / cv2 / tensorboard (absent here), so its loop body is restated on those classes."""
-    import emap_amd
-    from emap_amd import dropin, synthetic
-    dropin.install()
-    from src.models.udf_model import UDFNetwork, SingleVarianceNetwork, BetaNetwork      # = emap_amd's, through the aliases
-    from src.models.udf_renderer_blending import UDFRendererBlending
-    from src.models.loss import EdgeLoss
-    kw = dict(d_in=3, d_out=1, d_hidden=256, n_layers=8, skip_in=(4,), multires=10, bias=0.5)
-    udf_network = UDFNetwork(scale=1.0, **kw)
-    udf_network.load_state_dict(synthetic.make_udf_state(seed=42, pert=0.02, **kw))
-    udf_network = udf_network.to(dev)
-    udf_network.precision = precision
-    variance_network = SingleVarianceNetwork(0.3).to(dev)
-    beta_network = BetaNetwork(0.5, 0.3, 0.3, 5e-5, True, True, False).to(dev)
-    lr, lr_geo = 5e-4, 1e-4
-    if fused_adam:
-        from emap_amd.parallel import FusedAdam
-        optimizer = FusedAdam([{"params": list(udf_network.parameters()), "lr": lr_geo},
-                               {"params": list(variance_network.parameters()) + list(beta_network.parameters())}], lr=lr)
-    else:
-        optimizer = torch.optim.Adam([{"params": list(udf_network.parameters()), "lr": lr_geo},
-                                      {"params": list(variance_network.parameters()) + list(beta_network.parameters())},
-                                      {"params": []}], lr=lr)
-    renderer = UDFRendererBlending(None, udf_network, variance_network, beta_network, n_samples=n_samples, n_importance=n_importance,
-                                   n_outside=0, up_sample_steps=up_sample_steps, perturb=1.0, device=dev)
-    edge_loss_func = EdgeLoss("mse")
-    meta, edges = synthetic.make_scene(n_images=8, H=400, W=400, seed=3)
-    sampler = emap_amd.DeviceRaySampler.from_meta(meta, edges, device=dev, seed=1000)
-    near, far = float(meta["scene_box"]["near"]), float(meta["scene_box"]["far"])
-    edge_weight, igr_weight, igr_ns_weight = 1.0, 0.1, 0.0
-    state = {"iter": 0, "beta_flag": True, "loss": None}
-    image_perm = list(range(8))
+class SummaryWriter:
+    """What tensorboard's SummaryWriter.add_scalar does with its value (torch/utils/tensorboard/_convert_np.py: make_np ->
+    ``x.detach().cpu().numpy()``): a device tensor is READ at the call - one stream synchronisation each.  Nothing is written anywhere;
+    the reads are counted.  (tensorboard itself is not in this image; the name is what runner_udf.py:47 instantiates, so
+    emap_amd.dropin.train_wrapper finds and wraps it in this module exactly as it does in the runner's.)"""
+    device_reads = 0
 
-    def step():
-        it = state["iter"]
-        for g_, base in zip(optimizer.param_groups, (lr_geo, lr, lr)):      # update_learning_rate (runner_base.py:128-161): warm-up ramp
-            g_["lr"] = base * min(1.0, (it + 1) / 1000.0)
-        smp = sampler.gen_random_rays_patches_at(image_perm[it % len(image_perm)], rays, importance_sample=True)
+    def __init__(self, *a, **k):
+        self.rows = 0
+
+    def add_scalar(self, tag, scalar_value, global_step=None, *a, **k):
+        if isinstance(scalar_value, torch.Tensor):
+            if scalar_value.is_cuda:
+                SummaryWriter.device_reads += 1
+            scalar_value = float(scalar_value.detach().cpu().numpy())
+        self.rows += 1
+
+    def flush(self):
+        pass
+
+    def close(self):
+        pass
+
+
+class _RunnerLoop:
+    """The optimizer step AS THE REFERENCE'S RUNNER TAKES IT: the body of ``Runner_UDF.train_udf``'s loop (src/runner/runner_udf.py:63-186,
+    with runner_base.py:96-126's optimizer) restated statement by statement on the classes `emap_amd.dropin.install()` puts under
+    `src.models.*` - the runner module itself needs pyhocon / cv2 / tensorboard (absent here).  ``train_udf`` has the runner's shape
+    (creates ``self.writer = SummaryWriter(...)``, then loops), so ``emap_amd.dropin.train_wrapper`` applies to it unchanged."""
+
+    def __init__(self, dev, precision, rays, fused_adam, n_samples=64, n_importance=64, up_sample_steps=4):
+        import emap_amd
+        from emap_amd import dropin, synthetic
+        dropin.install()
+        from src.models.udf_model import UDFNetwork, SingleVarianceNetwork, BetaNetwork      # = emap_amd's, through the aliases
+        from src.models.udf_renderer_blending import UDFRendererBlending
+        from src.models.loss import EdgeLoss
+        kw = dict(d_in=3, d_out=1, d_hidden=256, n_layers=8, skip_in=(4,), multires=10, bias=0.5)
+        self.udf_network = UDFNetwork(scale=1.0, **kw)
+        self.udf_network.load_state_dict(synthetic.make_udf_state(seed=42, pert=0.02, **kw))
+        self.udf_network = self.udf_network.to(dev)
+        self.udf_network.precision = precision
+        self.variance_network_fine = SingleVarianceNetwork(0.3).to(dev)
+        self.beta_network = BetaNetwork(0.5, 0.3, 0.3, 5e-5, True, True, False).to(dev)
+        self.learning_rate, self.learning_rate_geo = 5e-4, 1e-4
+        groups = [{"params": list(self.udf_network.parameters()), "lr": self.learning_rate_geo},
+                  {"params": list(self.variance_network_fine.parameters()) + list(self.beta_network.parameters())}, {"params": []}]
+        if fused_adam:
+            from emap_amd.parallel import FusedAdam
+            self.optimizer = FusedAdam(groups[:2], lr=self.learning_rate)
+        else:
+            self.optimizer = torch.optim.Adam(groups, lr=self.learning_rate)
+        self.renderer = UDFRendererBlending(None, self.udf_network, self.variance_network_fine, self.beta_network, n_samples=n_samples,
+                                            n_importance=n_importance, n_outside=0, up_sample_steps=up_sample_steps, perturb=1.0, device=dev)
+        self.edge_loss_func = EdgeLoss("mse")
+        meta, edges = synthetic.make_scene(n_images=8, H=400, W=400, seed=3)
+        self.sampler = emap_amd.DeviceRaySampler.from_meta(meta, edges, device=dev, seed=1000)
+        self.near, self.far = float(meta["scene_box"]["near"]), float(meta["scene_box"]["far"])
+        self.edge_weight, self.igr_weight, self.igr_ns_weight = 1.0, 0.1, 0.0
+        self.batch_size, self.report_freq, self.iter_step = rays, 100, 0
+        self.image_perm = list(range(8))
+        self.beta_flag = True
+        self.writer = None
+        self.item_reads = 0
+        self.last_loss = None
+
+    def step(self):
+        it = self.iter_step
+        for g_, base in zip(self.optimizer.param_groups, (self.learning_rate_geo, self.learning_rate, self.learning_rate)):
+            g_["lr"] = base * min(1.0, (it + 1) / 1000.0)                      # update_learning_rate (runner_base.py:128-161): warm-up ramp
+        smp = self.sampler.gen_random_rays_patches_at(self.image_perm[it % len(self.image_perm)], self.batch_size, importance_sample=True)
         data = smp["rays"]
         rays_o, rays_d, true_edge = data["rays_o"], data["rays_v"], data["edge"]
         mask = torch.ones_like(true_edge).float()
         mask_sum = mask.sum() + 1e-5
-        out = renderer.render(rays_o, rays_d, near, far, depth_scale=smp["depth_scale"], flip_saturation=0.9, pose=None, fx=None, fy=None,
-                              img_index=None, cos_anneal_ratio=1.0)
-        udf, edge = out["udf"], out["edge"]
-        variance, beta = out["variance"], out["beta"]
-        udf_min = udf.min(dim=1)[0][mask[:, 0] > 0.5].mean()                   # noqa: F841  (the runner computes it for its log)
-        edge_loss = edge_loss_func(edge, true_edge) * edge_weight
-        psnr = 20.0 * torch.log10(1.0 / (((edge - true_edge) ** 2 * mask).sum() / mask_sum).sqrt())   # noqa: F841
-        if variance.mean() < 2 * beta.item() and variance.mean() < 0.01 and state["beta_flag"] and variance_network.variance.requires_grad:
-            beta_network.set_beta_trainable()
-            state["beta_flag"] = False
-        if variance_network.variance.requires_grad is False and it > 20000:
-            variance_network.set_trainable()
-        loss = edge_loss + out["gradient_error_near_surface"] * igr_ns_weight + out["gradient_error"] * igr_weight
-        state["loss"] = loss.item()                                            # the progress-bar read of runner_udf.py:164
-        optimizer.zero_grad()
+        render_out = self.renderer.render(rays_o, rays_d, self.near, self.far, depth_scale=smp["depth_scale"], flip_saturation=0.9, pose=None,
+                                          fx=None, fy=None, img_index=None, cos_anneal_ratio=1.0)
+        udf, edge = render_out["udf"], render_out["edge"]
+        variance, beta = render_out["variance"], render_out["beta"]
+        gradient_error, gradient_error_near_surface = render_out["gradient_error"], render_out["gradient_error_near_surface"]
+        udf_min = udf.min(dim=1)[0][mask[:, 0] > 0.5].mean()                   # noqa: F841  (the runner computes it too)
+        edge_loss = self.edge_loss_func(edge, true_edge) * self.edge_weight
+        psnr = 20.0 * torch.log10(1.0 / (((edge - true_edge) ** 2 * mask).sum() / mask_sum).sqrt())
+        gradient_error_loss = gradient_error
+        if (variance.mean() < 2 * beta.item() and variance.mean() < 0.01 and self.beta_flag
+                and self.variance_network_fine.variance.requires_grad):
+            self.beta_network.set_beta_trainable()
+            self.beta_flag = False
+        if self.variance_network_fine.variance.requires_grad is False and self.iter_step > 20000:
+            self.variance_network_fine.set_trainable()
+        igr_ns_weight = self.igr_ns_weight
+        loss = edge_loss + gradient_error_near_surface * igr_ns_weight + gradient_error_loss * self.igr_weight
+        self.last_loss = "PSNR: {:.2f}, Loss: {:.2f}".format(psnr, loss.item())  # par.set_description(...), runner_udf.py:164
+        self.optimizer.zero_grad()
         loss.backward()
-        optimizer.step()
-        state["iter"] = it + 1
+        self.optimizer.step()
+        self.iter_step += 1
+        w = self.writer
+        w.add_scalar("Loss/loss", loss, self.iter_step)
+        w.add_scalar("Loss/edge_loss", edge_loss, self.iter_step)
+        w.add_scalar("Loss/gradient_error_loss", gradient_error_loss * self.igr_weight, self.iter_step)
+        w.add_scalar("Loss/gradient_error_near_surface", gradient_error_near_surface * igr_ns_weight, self.iter_step)
+        w.add_scalar("Sta/variance", variance.mean(), self.iter_step)
+        w.add_scalar("Sta/beta", beta.item(), self.iter_step)
+        w.add_scalar("Sta/psnr", psnr, self.iter_step)
 
-    S = renderer.samples_per_ray
-    dt, med = _timed(step, steps, warmup)
-    renderer.check_errors()
-    return {"metric": "ray-samples/sec (the reference runner's own step on the drop-in classes: autograd render + EdgeLoss + .item() reads + "
-                      + ("emap_amd FusedAdam" if fused_adam else "torch.optim.Adam") + ")",
+    def train_udf(self, timed):
+        self.writer = SummaryWriter(log_dir=None)                              # runner_udf.py:47
+        return timed(self.step)
+
+
+def train_dropin_key(dev, precision, rays, steps=40, warmup=10, n_samples=64, n_importance=64, up_sample_steps=4, fused_adam=False,
+                     patched=False):
+    """See _RunnerLoop.  `patched`: ``emap_amd.dropin.train_wrapper`` around the SAME ``train_udf`` (what ``dropin.patch_runner(train=True)``
+    does to ``Runner_UDF``): host-mirrored variance / beta / gamma, gradients installed by RenderFn, FusedAdam swapped in, deferred
+    tensorboard scalars.  Host reads of device values per step are counted (writer) + known (.item() / format / bool of the loop body)."""
+    from emap_amd import dropin
+    loop = _RunnerLoop(dev, precision, rays, fused_adam, n_samples, n_importance, up_sample_steps)
+    S = loop.renderer.samples_per_ray
+    SummaryWriter.device_reads = 0
+    run = lambda step: _timed(step, steps, warmup)
+    train = _RunnerLoop.train_udf
+    if patched:
+        train = dropin.train_wrapper(train, sys.modules[__name__])
+    dt, med = train(loop, run)
+    loop.renderer.check_errors()
+    n_steps = steps + warmup
+    writer_reads = SummaryWriter.device_reads / n_steps
+    # loop body: unpatched - beta.item(), bool(variance.mean() < ...), format(psnr), loss.item(), beta.item() for the writer = 5 reads of
+    # device tensors, each a stream synchronisation (the first waits for the forward, the fourth too after the loss kernels); patched -
+    # format(psnr) + loss.item(): two reads behind ONE wait for the forward
+    body_reads = 2 if patched else 5
+    return {"metric": "ray-samples/sec (the reference runner's own step on the drop-in classes: autograd render + EdgeLoss + host reads + "
+                      + (type(loop.optimizer).__name__) + (", emap_amd.dropin.train_wrapper" if patched else "") + ")",
             "rays": rays, "samples_per_ray": S, "steps": steps, "warmup": warmup, "ms_per_step": dt * 1e3, "ms_per_step_median": med,
-            "value": rays * S / dt, "unit": "ray-samples/s", "host_syncs_per_step": 4, "loss_after_run": state["loss"],
-            "reference": "src/runner/runner_udf.py:63-168, runner_base.py:96-126"}
+            "value": rays * S / dt, "unit": "ray-samples/s", "optimizer": type(loop.optimizer).__name__, "patched": bool(patched),
+            "host_syncs_per_step": body_reads + writer_reads, "host_waits_for_the_forward_per_step": 1 if patched else 2,
+            "writer_device_reads_per_step": writer_reads, "last_progress_text": loop.last_loss,
+            "reference": "src/runner/runner_udf.py:63-186, runner_base.py:96-126"}
 
 
 def default_shape_key(dev, precision, steps=40, warmup=10):
@@ -472,14 +537,16 @@ def main():
         # the reference runner's own optimizer step on the drop-in classes (one GPU: EMAP itself is single-GPU)
         if world != 1:
             raise SystemExit("bench.py --path dropin runs on one GPU (the reference's loop has no data parallelism)")
-        res = train_dropin_key(dev, a.precision, rays, steps=a.steps, warmup=a.warmup + a.settle_steps // 10, fused_adam=(a.path == "dropin-fused"))
+        res = train_dropin_key(dev, a.precision, rays, steps=a.steps, warmup=a.warmup + a.settle_steps // 10, fused_adam=(a.path == "dropin-fused"),
+                               patched=(a.path == "dropin-patched"))
         line = {"metric": res["metric"], "value": res["value"], "unit": "ray-samples/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
                 "ms_per_step": res["ms_per_step"], "ms_per_step_median": res["ms_per_step_median"], "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": MODE_DTYPE[a.precision], "data": "synthetic",
                 "config": {"workload": f"{rays} rays x {res['samples_per_ray']} samples, UDF MLP d=8 w=256 multires=10, optimizer step as "
                                        f"src/runner/runner_udf.py:63-168 takes it, on the drop-in classes ({a.path})",
-                           "mode": "train", "path": a.path, "precision": a.precision, "host_syncs_per_step": res["host_syncs_per_step"]},
-                "whole_step_frac_of_mfma_peak": res["value"] * A_TRAIN / 1e12 / MFMA_PEAK_TFLOPS, "loss_after_run": res["loss_after_run"]}
+                           "mode": "train", "path": a.path, "precision": a.precision, "host_syncs_per_step": res["host_syncs_per_step"],
+                           "host_waits_for_the_forward_per_step": res["host_waits_for_the_forward_per_step"]},
+                "whole_step_frac_of_mfma_peak": res["value"] * A_TRAIN / 1e12 / MFMA_PEAK_TFLOPS, "last_progress_text": res["last_progress_text"]}
         print(json.dumps(line), flush=True)
         return
 
@@ -729,8 +796,10 @@ def main():
             try:    # the reference runner's own step through the drop-in classes
                 line["train_dropin"] = train_dropin_key(dev, a.precision, rays)
                 line["train_dropin_fused_adam"] = train_dropin_key(dev, a.precision, rays, fused_adam=True)
+                # round 5: the same loop under emap_amd.dropin.train_wrapper (= dropin.patch_runner(train=True) on Runner_UDF)
+                line["train_dropin_patched"] = train_dropin_key(dev, a.precision, rays, patched=True)
                 if isinstance(line.get("train"), dict) and line["train"].get("ms_per_step"):
-                    for k in ("train_dropin", "train_dropin_fused_adam"):
+                    for k in ("train_dropin", "train_dropin_fused_adam", "train_dropin_patched"):
                         line[k]["vs_native_trainer"] = line[k]["ms_per_step"] / line["train"]["ms_per_step"]
             except Exception as e:
                 line["train_dropin"] = {"error": repr(e)}

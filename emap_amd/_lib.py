@@ -22,7 +22,7 @@ PREC_F16X3M = 4    # f16x3 with MX-fp6 cross terms in the forward sweep of the v
 PRECISIONS = {"bf16": PREC_BF16, "bf16x3": PREC_BF16X3, "f16": PREC_F16, "f16x3": PREC_F16X3, "f16x3m": PREC_F16X3M}
 UDF_TYPES = {"abs": 0, "square": 1, "sdf": 2}
 MAX_LIN = 12
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 F_NAN_SAMPLES = 1
 F_NAN_GRADERR = 2
@@ -111,8 +111,8 @@ SYMBOLS = {
     "emap_sample_rays": (C.c_int, [C.POINTER(RayDataset), C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, _P, _P, C.POINTER(RayBatch), _P]),
     "emap_train_stats": (C.c_int, [_P, _P, _P, C.c_int, C.c_float, _P, _P, _P]),
     "emap_train_loss": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, _P, _P]),
-    "emap_adam_step": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
-    "emap_adam_step_masked": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P, _P]),
+    "emap_adam_step": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_double, C.c_double, C.c_float, _P]),
+    "emap_adam_step_masked": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_double, C.c_double, C.c_float, _P, _P, _P]),
     "emap_profile_enable": (C.c_int, [C.c_int]),
     "emap_profile_read": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "emap_profile_read_kernel": (C.c_int, [C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]),

@@ -46,6 +46,17 @@ class ParamLayout:
 
     def tables(self, flat: torch.Tensor):
         """(ParamGrads struct, keep-alive list) with the d* tables pointing into `flat`."""
+        ck = (flat.data_ptr(), tuple(t.data_ptr() for t in self.vs + (self.gs if self.weight_norm else [])))
+        hit = getattr(self, "_tables_hit", None)
+        if hit is not None and hit[0] == ck:            # a persistent gradient buffer (Trainer, direct_param_grads): same tables every step
+            pg, keep = hit[1]
+            pg.accumulate, pg.grad_scale = 0, 1.0
+            return pg, keep
+        pg, keep = self._tables(flat)
+        self._tables_hit = (ck, (pg, keep))
+        return pg, keep
+
+    def _tables(self, flat: torch.Tensor):
         n = self.n_lin
         es = flat.element_size()
         base = flat.data_ptr()
@@ -189,12 +200,26 @@ class RenderFn(torch.autograd.Function):
                     f"emap_amd: the loss depends on render()['{k}'], whose gradient the HIP backward does not provide "
                     "(differentiable outputs: edge, depth, gradient_error, gradient_error_near_surface, variance, beta, gamma)")
         r, call, v = ctx.renderer, ctx.call, ctx.v
-        r.udf_network.packed(call["prec_name"])
+        packed = r.udf_network.packed(call["prec_name"])
         if r.udf_network._pack_cache[_lib.PRECISIONS[call["prec_name"]]][0] != ctx.packed_key:
             raise RuntimeError("emap_amd: the UDF network's parameters changed between render() and backward() (an optimizer step or an "
                                "in-place edit in between): the gradient would be taken at other weights than the forward used")
-        flat = r.backward_into(call, v, d_edge, d_depth, d_ge, d_ge_ns)
         lay = r._layout()
         need = [p.requires_grad for p in lay.tensors]
         ctx.v = None
+        if getattr(r, "direct_param_grads", False) and all(p.grad is None for p, nd in zip(lay.tensors, need) if nd):
+            # Fast path of the drop-in training step (dropin.patch_runner(train=True)): the kernels write into ONE persistent flat buffer
+            # and its views become the parameters' .grad here; autograd gets None for them.  Handing the 32 views to autograd instead makes
+            # every AccumulateGrad node clone its view (32 small copy kernels + their launches per step) and the optimizer re-gather them.
+            # Only when no parameter holds a gradient yet (zero_grad(set_to_none=True), the default): accumulation into existing
+            # gradients takes the ordinary path below.  The buffer is overwritten by the next backward of this renderer.
+            G = getattr(r, "_grad_flat", None)
+            if G is None or G.numel() != lay.numel or G.device != call["dev"]:
+                G = r._grad_flat = torch.empty(lay.numel, dtype=torch.float32, device=call["dev"])
+            r.backward_into(call, v, d_edge, d_depth, d_ge, d_ge_ns, flat=G, packed=packed)
+            for p, g_ in zip(lay.tensors, lay.views(G, need)):
+                if g_ is not None:
+                    p.grad = g_
+            return (None, None) + (None,) * len(lay.tensors)
+        flat = r.backward_into(call, v, d_edge, d_depth, d_ge, d_ge_ns, packed=packed)
         return (None, None) + tuple(lay.views(flat, need))

@@ -64,7 +64,7 @@ int launch_composite_bwd(const float*, const float*, const float*, const float*,
 // ---- scalar tail of a training step (train.hip) ----
 int launch_train_stats(const float*, const float*, const float*, int, float, float*, float*, hipStream_t);
 int launch_train_loss(const float*, float, float, float, float*, hipStream_t);
-int launch_adam(float*, const float*, float*, float*, float*, int64_t, int64_t, float, float, float, float, float, const float*, float*, hipStream_t);
+int launch_adam(float*, const float*, float*, float*, float*, int64_t, int64_t, float, float, double, double, float, const float*, float*, hipStream_t);
 // ---- training backward (udf_mlp_vjp.inc, wgrad.hip) ----
 #define EMAP_VJP_DECL(m) \
     int launch_vjp_sweep_##m(const NetLayout&, const void*, const PointSource&, int64_t, int, int, const float*, const float*, \
@@ -556,11 +556,11 @@ int emap_train_loss(const float* stats5, float w_over_n, float igr_weight, float
     return launch_train_loss(stats5, w_over_n, igr_weight, igr_ns_weight, out2, static_cast<hipStream_t>(stream));
 }
 int emap_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* step_dev, int64_t n, int64_t n_geo,
-                   float lr_geo, float lr, float beta1, float beta2, float eps, void* stream) {
+                   float lr_geo, float lr, double beta1, double beta2, float eps, void* stream) {
     return launch_adam(params, grads, exp_avg, exp_avg_sq, step_dev, n, n_geo, lr_geo, lr, beta1, beta2, eps, nullptr, nullptr, static_cast<hipStream_t>(stream));
 }
 int emap_adam_step_masked(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* step_dev, int64_t n, int64_t n_geo,
-                          float lr_geo, float lr, float beta1, float beta2, float eps, const float* tail_mask, float* tail_step, void* stream) {
+                          float lr_geo, float lr, double beta1, double beta2, float eps, const float* tail_mask, float* tail_step, void* stream) {
     return launch_adam(params, grads, exp_avg, exp_avg_sq, step_dev, n, n_geo, lr_geo, lr, beta1, beta2, eps, tail_mask, tail_step,
                        static_cast<hipStream_t>(stream));
 }

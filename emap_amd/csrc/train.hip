@@ -42,22 +42,25 @@ __global__ void train_loss_kernel(const float* stats, float w_over_n, float igr,
 // tail_mask / tail_step (may be null: every element trainable, one global step count): per element of the tail [n_geo, n) - the
 // scalars variance / beta / gamma - whether it is trainable (requires_grad) and its OWN step count: torch.optim.Adam skips a parameter
 // without gradient and starts its `step` state when the parameter first gets one (runner_udf.py:144-154 un-freezes variance / beta late)
+// b1, b2 arrive as DOUBLES and 1 - b, b^t are formed in double like torch does (python floats / the fused kernel's double arguments):
+// 1.0f - 0.999f is 4.7e-5 off 0.001, which scaled exp_avg_sq by that factor against a torch.optim.Adam checkpoint (round 5).
 __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, float* step, long long n, long long n_geo,
-                                                   float lr_geo, float lr, float b1, float b2, float eps, const float* tail_mask,
+                                                   float lr_geo, float lr, double b1d, double b2d, float eps, const float* tail_mask,
                                                    float* tail_step) {
     const float t = *step + 1.0f;
-    const float bc1 = 1.0f - powf(b1, t), bc2s = sqrtf(1.0f - powf(b2, t));
+    const float b2 = (float)b2d, omb1 = (float)(1.0 - b1d), omb2 = (float)(1.0 - b2d);
+    const float bc1 = (float)(1.0 - pow(b1d, (double)t)), bc2s = (float)sqrt(1.0 - pow(b2d, (double)t));
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         float c1 = bc1, c2s = bc2s;
         if (i >= n_geo && tail_mask) {
             if (tail_mask[i - n_geo] == 0.0f) continue;                  // frozen: no update, no state change
             const float tt = tail_step[i - n_geo] + 1.0f;
             tail_step[i - n_geo] = tt;
-            c1 = 1.0f - powf(b1, tt); c2s = sqrtf(1.0f - powf(b2, tt));
+            c1 = (float)(1.0 - pow(b1d, (double)tt)); c2s = (float)sqrt(1.0 - pow(b2d, (double)tt));
         }
         const float gi = g[i];
-        const float mi = m[i] + (gi - m[i]) * (1.0f - b1);
-        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        const float mi = m[i] + (gi - m[i]) * omb1;
+        const float vi = b2 * v[i] + omb2 * gi * gi;
         m[i] = mi; v[i] = vi;
         const float step_size = ((i < n_geo) ? lr_geo : lr) / c1;
         p[i] -= step_size * mi / (sqrtf(vi) / c2s + eps);
@@ -76,8 +79,8 @@ int launch_train_loss(const float* stats, float w_over_n, float igr, float igr_n
     hipLaunchKernelGGL(train_loss_kernel, dim3(1), dim3(1), 0, st, stats, w_over_n, igr, igr_ns, out);
     return check_launch("train_loss");
 }
-int launch_adam(float* p, const float* g, float* m, float* v, float* step, int64_t n, int64_t n_geo, float lr_geo, float lr, float b1,
-                float b2, float eps, const float* tail_mask, float* tail_step, hipStream_t st) {
+int launch_adam(float* p, const float* g, float* m, float* v, float* step, int64_t n, int64_t n_geo, float lr_geo, float lr, double b1,
+                double b2, float eps, const float* tail_mask, float* tail_step, hipStream_t st) {
     if (!p || !g || !m || !v || !step || n < 0 || n_geo < 0 || n_geo > n || ((tail_mask == nullptr) != (tail_step == nullptr))) {
         set_error("adam_step: bad arguments");
         return EMAP_E_INVALID;

@@ -92,12 +92,105 @@ def _patch_dataset():
     return True
 
 
-def _patch_runner():
+class DeferredScalarWriter:
+    """Stands in for the runner's ``SummaryWriter`` (runner_udf.py:47): ``add_scalar(tag, value, step)`` with a DEVICE tensor does
+    not read it (tensorboard's ``make_np`` is ``value.cpu()``: a stream synchronisation per call, seven per step at runner_udf.py:172-186)
+    but keeps the 0-dim tensor; every ``flush_every`` steps - and on ``flush()`` / ``close()`` - the pending values travel in ONE copy
+    and are handed to the real writer with their original tags and steps, in order.  Python numbers and host tensors pass through
+    unchanged, as does every other method."""
+
+    def __init__(self, writer, flush_every: int = 100, max_pending: int = 4096):
+        self._w, self._every, self._max = writer, max(int(flush_every), 1), int(max_pending)
+        self._pending, self._last_flush_step = [], None
+
+    def add_scalar(self, tag, scalar_value, global_step=None, *a, **k):
+        import torch
+        if isinstance(scalar_value, torch.Tensor) and scalar_value.is_cuda:
+            if getattr(scalar_value, "_emap_host", None) is not None:     # a host-mirrored scalar (host_scalars.py): its value is on the host already
+                scalar_value = float(scalar_value)
+            else:
+                self._pending.append((tag, scalar_value.detach().reshape(-1)[:1], global_step, a, k))
+                if self._last_flush_step is None:
+                    self._last_flush_step = global_step if isinstance(global_step, int) else 0
+                due = isinstance(global_step, int) and global_step - self._last_flush_step >= self._every
+                if due or len(self._pending) >= self._max:
+                    self.flush_pending()
+                    self._last_flush_step = global_step if isinstance(global_step, int) else 0
+                return None
+        if self._pending:                  # rows reach the real writer in the order the runner issued them
+            self._pending.append((tag, scalar_value, global_step, a, k))
+            return None
+        return self._w.add_scalar(tag, scalar_value, global_step, *a, **k)
+
+    def flush_pending(self):
+        import torch
+        if not self._pending:
+            return
+        dev = [p[1] for p in self._pending if isinstance(p[1], torch.Tensor) and p[1].is_cuda]
+        vals = iter(torch.cat(dev).float().cpu().tolist()) if dev else iter(())      # one device-to-host copy
+        for tag, v, step, a, k in self._pending:
+            self._w.add_scalar(tag, next(vals) if (isinstance(v, torch.Tensor) and v.is_cuda) else v, step, *a, **k)
+        self._pending = []
+
+    def flush(self):
+        self.flush_pending()
+        return self._w.flush() if hasattr(self._w, "flush") else None
+
+    def close(self):
+        self.flush_pending()
+        return self._w.close() if hasattr(self._w, "close") else None
+
+    def __getattr__(self, name):
+        return getattr(self._w, name)
+
+
+def train_wrapper(orig_train, mod=None, fused_adam: bool = True, defer_scalars: bool = True):
+    """``Runner_UDF.train_udf`` (src/runner/runner_udf.py:35-250) unmodified, with the host-side cost of its step removed where
+    that is possible without touching its code:
+      * the renderer hands out host-mirrored ``variance / beta / gamma`` (host_scalars.py): the reads of runner_udf.py:141-148,185 do not
+        wait for the forward render, so the runner's own small loss kernels queue up behind it instead of after a synchronisation;
+      * ``RenderFn.backward`` installs the parameter gradients itself (``direct_param_grads``) and ``FusedAdam`` (swapped in for the
+        runner's ``torch.optim.Adam`` over the same groups: one launch instead of 32 x 6) reads them in place;
+      * the tensorboard writer the method creates defers device scalars (``DeferredScalarWriter``, flushed every ``report_freq`` steps).
+    What stays: the progress bar's ``loss.item()`` / ``format(psnr)`` (runner_udf.py:164) - one wait for the forward per step."""
+    def train_udf(self, *a, **k):
+        import torch
+        from .parallel import FusedAdam
+        r = self.renderer
+        old = (getattr(r, "host_mirror_scalars", False), getattr(r, "direct_param_grads", False))
+        r.host_mirror_scalars, r.direct_param_grads = True, True
+        if fused_adam and isinstance(self.optimizer, torch.optim.Adam) and torch.device(getattr(r, "device", "cuda")).type == "cuda":
+            self.optimizer = FusedAdam.from_adam(self.optimizer)
+        m = mod if mod is not None else sys.modules.get(type(self).__module__)
+        sw = getattr(m, "SummaryWriter", None) if m is not None else None
+        if defer_scalars and sw is not None:
+            every = int(getattr(self, "report_freq", 100) or 100)
+            m.SummaryWriter = lambda *wa, **wk: DeferredScalarWriter(sw(*wa, **wk), flush_every=every)
+        try:
+            return orig_train(self, *a, **k)
+        finally:
+            if defer_scalars and sw is not None:
+                m.SummaryWriter = sw
+            w = getattr(self, "writer", None)
+            if isinstance(w, DeferredScalarWriter):
+                w.flush_pending()
+            r.host_mirror_scalars, r.direct_param_grads = old
+    train_udf.__wrapped__ = orig_train
+    return train_udf
+
+
+def _patch_runner(train: bool = False):
     mod = sys.modules.get("src.runner.runner_udf")   # patched only if the caller has it imported (it imports src.models.* itself)
-    if mod is None or not hasattr(mod, "Runner_UDF") or hasattr(mod.Runner_UDF.validate, "__wrapped__"):
+    if mod is None or not hasattr(mod, "Runner_UDF"):
         return False
-    mod.Runner_UDF.validate = validate_wrapper(mod.Runner_UDF.validate)
-    return True
+    done = False
+    if not hasattr(mod.Runner_UDF.validate, "__wrapped__"):
+        mod.Runner_UDF.validate = validate_wrapper(mod.Runner_UDF.validate)
+        done = True
+    if train and hasattr(mod.Runner_UDF, "train_udf") and not hasattr(mod.Runner_UDF.train_udf, "__wrapped__"):
+        mod.Runner_UDF.train_udf = train_wrapper(mod.Runner_UDF.train_udf, mod)
+        done = True
+    return done
 
 
 def install(force: bool = True, patch_dataset: bool = True):
@@ -131,6 +224,7 @@ def install(force: bool = True, patch_dataset: bool = True):
     return sorted(_ALIASES)
 
 
-def patch_runner():
-    """Call after ``from src.runner.runner_udf import Runner_UDF``: wraps ``Runner_UDF.validate`` (see validate_wrapper)."""
-    return _patch_runner()
+def patch_runner(train: bool = False):
+    """Call after ``from src.runner.runner_udf import Runner_UDF``: wraps ``Runner_UDF.validate`` (see validate_wrapper) and, with
+    ``train=True``, ``Runner_UDF.train_udf`` (see train_wrapper)."""
+    return _patch_runner(train)

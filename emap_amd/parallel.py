@@ -464,6 +464,21 @@ class FusedAdam(torch.optim.Optimizer):
             raise ValueError("FusedAdam: the groups behind the first one must share one learning rate (the runner's do)")
         self._flat = None
 
+    @classmethod
+    def from_adam(cls, adam: torch.optim.Optimizer) -> "FusedAdam":
+        """A FusedAdam over the SAME parameter groups as a ``torch.optim.Adam`` (runner_base.py:106-117), taking over its learning rates,
+        betas, eps and - if it has stepped already - its state (checkpoint layout, load_state_dict)."""
+        groups = []
+        for g in adam.param_groups:
+            if g.get("amsgrad") or g.get("weight_decay") or g.get("maximize"):
+                raise NotImplementedError("FusedAdam.from_adam: amsgrad / weight_decay / maximize are not implemented")
+            groups.append({"params": list(g["params"]), "lr": g["lr"], "betas": tuple(g["betas"]), "eps": g["eps"]})
+        g0 = next(g for g in groups if g["params"])
+        opt = cls(groups, lr=g0["lr"], betas=g0["betas"], eps=g0["eps"])
+        if len(adam.state):
+            opt.load_state_dict(adam.state_dict())
+        return opt
+
     def _build(self):
         geo = list(self._geo_group["params"])
         tail = [p for g in self._tail_groups for p in g["params"]]
@@ -540,10 +555,20 @@ class FusedAdam(torch.optim.Optimizer):
             self._build()
         dev = self._flat.data.device
         parts = []
+        # the geometry gradients may already BE one flat buffer (RenderFn.backward with direct_param_grads, or a Trainer-style caller):
+        # consecutive fp32 views in this optimizer's order -> no gather
+        geo_ptr, off = None, 0
         for p in self._geo:
-            if p.grad is None:
+            g_ = p.grad
+            if g_ is None:
                 raise NotImplementedError("FusedAdam: a parameter of the first group without gradient")
-            parts.append(p.grad.reshape(-1))
+            if off == 0:
+                geo_ptr = g_.data_ptr()
+            if geo_ptr is not None and (g_.dtype != torch.float32 or not g_.is_contiguous() or g_.data_ptr() != geo_ptr + 4 * off):
+                geo_ptr = None
+            off += p.numel()
+        if geo_ptr is None:
+            parts = [p.grad.reshape(-1) for p in self._geo]
         flags = []
         for p in self._tail:
             has = p.grad is not None
@@ -558,15 +583,32 @@ class FusedAdam(torch.optim.Optimizer):
         if flags != self._flags:                # rare: a set_trainable() of the runner
             self._tail_mask[:len(flags)].copy_(torch.tensor(flags))
             self._flags = flags
-        grad = torch.cat(parts)
         lr_tail = self._tail_groups[0]["lr"] if self._tail_groups else self._geo_group["lr"]
         b1, b2 = self._geo_group["betas"]
+        L, st = _lib.lib(), _lib.stream_ptr(dev)
         with torch.cuda.device(dev):
-            _lib.check(_lib.lib().emap_adam_step_masked(_lib.ptr(self._flat.data), _lib.ptr(grad), _lib.ptr(self._m), _lib.ptr(self._v),
-                                                        _lib.ptr(self._t), self._flat.numel, self._n_geo, float(self._geo_group["lr"]),
-                                                        float(lr_tail), float(b1), float(b2), float(self._geo_group["eps"]),
-                                                        _lib.ptr(self._tail_mask), _lib.ptr(self._tail_step), _lib.stream_ptr(dev)),
-                       "adam_step")
+            if geo_ptr is None:
+                grad = torch.cat(parts)
+                _lib.check(L.emap_adam_step_masked(_lib.ptr(self._flat.data), _lib.ptr(grad), _lib.ptr(self._m), _lib.ptr(self._v),
+                                                   _lib.ptr(self._t), self._flat.numel, self._n_geo, float(self._geo_group["lr"]),
+                                                   float(lr_tail), float(b1), float(b2), float(self._geo_group["eps"]),
+                                                   _lib.ptr(self._tail_mask), _lib.ptr(self._tail_step), st), "adam_step")
+            else:
+                # two launches on disjoint ranges, same arithmetic: the geometry range straight from the caller's flat gradient buffer
+                # (its step counter self._t is bumped by this call), the few tail scalars gathered as before (their own step counts)
+                import ctypes as C
+                ng, nt = self._n_geo, self._flat.numel - self._n_geo
+                _lib.check(L.emap_adam_step(_lib.ptr(self._flat.data), C.c_void_p(geo_ptr), _lib.ptr(self._m), _lib.ptr(self._v),
+                                            _lib.ptr(self._t), ng, ng, float(self._geo_group["lr"]), float(lr_tail), float(b1), float(b2),
+                                            float(self._geo_group["eps"]), st), "adam_step")
+                if nt > 0:
+                    gt = torch.cat(parts)
+                    if getattr(self, "_t_tail_dummy", None) is None:
+                        self._t_tail_dummy = torch.zeros(1, device=dev)
+                    _lib.check(L.emap_adam_step_masked(_lib.ptr(self._flat.data[ng:]), _lib.ptr(gt), _lib.ptr(self._m[ng:]), _lib.ptr(self._v[ng:]),
+                                                       _lib.ptr(self._t_tail_dummy), nt, 0, float(self._geo_group["lr"]), float(lr_tail),
+                                                       float(b1), float(b2), float(self._geo_group["eps"]), _lib.ptr(self._tail_mask),
+                                                       _lib.ptr(self._tail_step), st), "adam_step")
         # the in-place flat update is invisible to the per-tensor version counters UDFNetwork.packed() keys its fragment cache on
         inc = getattr(torch.autograd.graph, "increment_version", None)
         for p in self._geo:

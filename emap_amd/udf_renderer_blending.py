@@ -114,9 +114,14 @@ class UDFRendererBlending:
         self.device = device
         self.precision = precision  # None -> udf_network.precision
         self.inference_reduced = False   # True: render() without autograd returns per-ray results only (_render_reduced_compat)
+        # drop-in training step (emap_amd.dropin.patch_runner(train=True) sets both; host_scalars.py / backward.py:RenderFn):
+        self.host_mirror_scalars = False  # variance / beta / gamma of the render dict answer host reads from a pinned copy made BEFORE the forward
+        self.direct_param_grads = False   # RenderFn.backward installs its flat gradient buffer's views as .grad itself (no 32 AccumulateGrad clones)
+        self._mirror = None
         self._ws = {}
         self._ws_pool = {}
         self._bws = {}
+        self._bws_bytes = {}
         self._err = None
         self._lay = None
         self._const = {}
@@ -272,7 +277,7 @@ class UDFRendererBlending:
         return v
 
     def backward_into(self, call, v, d_edge, d_depth=None, d_ge=None, d_ge_ns=None, flat=None, scalars=None, grad_scale=1.0,
-                      stages=3):
+                      stages=3, packed=None):
         """One emap_render_bwd call: parameter gradients of  sum(d_edge*edge) + sum(d_depth*depth) + d_ge*gradient_error +
         d_ge_ns*gradient_error_near_surface  into `flat` (parameters() order of the UDF network, then variance, beta,
         gamma; allocated when None).  `scalars`: the forward's scalars, or a copy with GLOBAL eikonal mask sums in [4],[6]
@@ -307,12 +312,18 @@ class UDFRendererBlending:
         p = call["p"]
         L = _lib.lib()
         cfg = net.net_config()
+        if packed is None:
+            packed = net.packed(call["prec_name"])
         with _lib.on_device(call["ro"]):
-            nb = C.c_size_t()
-            _lib.check(L.emap_render_bwd_workspace_bytes(C.byref(cfg), prec, C.byref(p), C.byref(nb)), "render_bwd_workspace_bytes")
+            nbk = (N, S, prec, self.n_samples, self.n_importance, self.up_sample_steps)
+            nbv = self._bws_bytes.get(nbk)
+            if nbv is None:
+                nb = C.c_size_t()
+                _lib.check(L.emap_render_bwd_workspace_bytes(C.byref(cfg), prec, C.byref(p), C.byref(nb)), "render_bwd_workspace_bytes")
+                nbv = self._bws_bytes[nbk] = nb.value
             lim = net.backward_workspace_limit
-            ws = _workspace(self._bws, (N, S, prec), nb.value if lim is None else min(nb.value, int(lim)), dev)
-            _lib.check(L.emap_render_bwd_staged(C.byref(cfg), _lib.ptr(net.packed(call["prec_name"])), prec, C.byref(p),
+            ws = _workspace(self._bws, (N, S, prec), nbv if lim is None else min(nbv, int(lim)), dev)
+            _lib.check(L.emap_render_bwd_staged(C.byref(cfg), _lib.ptr(packed), prec, C.byref(p),
                                                 _lib.ptr(call["ro"]), _lib.ptr(call["rd"]), _lib.ptr(call["ds"]), _lib.ptr(v["z_vals"]),
                                                 _lib.ptr(v["udf"]), _lib.ptr(v["gradients"]), _lib.ptr(v.get("_sd", v["_ws"])), C.byref(cg), C.byref(pg),
                                                 _lib.ptr(ws), ws.numel() if lim is None else min(ws.numel(), int(lim)), _lib.ptr(self._err),
@@ -355,6 +366,20 @@ class UDFRendererBlending:
                              flip_saturation, t_rand)
         N, S, dev = call["N"], call["S"], call["dev"]
         train = self._trainable()
+        extras_train = train and any(q.requires_grad for q in self._layout().extra)
+        pre = None
+        if extras_train or (train and self.host_mirror_scalars):
+            # variance / beta / gamma as ordinary torch expressions (:466-472,656-658): differentiable when the scalars are trainable.
+            # Evaluated BEFORE the forward is enqueued: they depend on the parameters only, and with host_mirror_scalars their values start
+            # travelling to a pinned buffer now, so the runner's host reads of them (runner_udf.py:141-148) do not wait for the render.
+            with torch.set_grad_enabled(extras_train):
+                inv_s = self.deviation_network(torch.zeros([1, 3], device=dev))[:, :1].clip(1e-6, 1e6)
+                pre = (1.0 / inv_s, 1.0 / self.beta_network.get_beta().clip(1e-6, 1e6), self.beta_network.get_gamma().clip(1e-6, 1e6))
+            if self.host_mirror_scalars:
+                if self._mirror is None or self._mirror.dev != dev:
+                    from .host_scalars import ScalarMirror
+                    self._mirror = ScalarMirror(dev)
+                mirror = self._mirror.push(torch.cat([q.detach().reshape(1) for q in pre]))
         if train:
             lay = self._layout()
             res = RenderFn.apply(self, call, *lay.tensors)
@@ -371,17 +396,17 @@ class UDFRendererBlending:
         if train:
             out.update(dict(zip(RenderFn.DIFF + RenderFn.GUARDED, res)))
         sc = v["scalars"]
-        if train and any(q.requires_grad for q in self._layout().extra):
-            # differentiable w.r.t. variance/beta/gamma: ordinary torch expressions (:466-472,656-658)
-            inv_s = self.deviation_network(torch.zeros([1, 3], device=dev))[:, :1].clip(1e-6, 1e6)
-            s_val = (1.0 / inv_s).expand(N * S, 1)
-            beta_out = 1.0 / self.beta_network.get_beta().clip(1e-6, 1e6)
-            gamma_out = self.beta_network.get_gamma().clip(1e-6, 1e6)
+        if extras_train:
+            s_val, beta_out, gamma_out = pre[0].expand(N * S, 1), pre[1], pre[2]
         else:
             # the same three numbers, written by the compositing kernel (no extra launches)
             s_val = sc[8:9].view(1, 1).expand(N * S, 1)
             beta_out = sc[9:10]
             gamma_out = sc[10:11]
+        if pre is not None and self.host_mirror_scalars:
+            from .host_scalars import HostScalar, LazyMaskable
+            s_val, beta_out, gamma_out = (HostScalar.wrap(q, mirror[0], i, mirror[1]) for i, q in enumerate((s_val, beta_out, gamma_out)))
+            out["udf"] = out["udf"].as_subclass(LazyMaskable)     # runner_udf.py:126 indexes a reduction of it with a boolean mask: no sync for that
         return {
             "udf": out["udf"], "edge": out["edge"], "weight_sum": out["weight_sum"], "weight_sum_fg_bg": out["weight_sum"],
             "depth": out["depth"], "variance": s_val, "beta": beta_out, "gamma": gamma_out,

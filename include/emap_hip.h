@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EMAP_ABI_VERSION 6
+#define EMAP_ABI_VERSION 7
 
 /* error codes */
 #define EMAP_OK 0
@@ -319,19 +319,21 @@ int emap_sample_rays(const EmapRayDataset* ds, int img_idx, int batch, int impor
  *                      loss = edge_loss + igr * stats5[2] / (stats5[0] + 1e-5) + igr_ns * stats5[3] / (stats5[1] + 1e-5)
  * emap_adam_step   : torch.optim.Adam([{geo params, lr_geo}, {the rest}], lr) (runner_base.py:110-117; betas / eps as given,
  *                    no weight decay, no amsgrad) on flat buffers: elements [0, n_geo) use lr_geo, [n_geo, n) use lr.
- *                    `step_dev` (float[1], starts at 0) counts the steps on the device and is incremented by the call. */
+ *                    `step_dev` (float[1], starts at 0) counts the steps on the device and is incremented by the call.
+ *                    ABI 7: beta1 / beta2 are DOUBLES - 1 - beta and beta^t are formed in double as torch forms them (1.0f - 0.999f is
+ *                    4.7e-5 off 0.001: exp_avg_sq would not match a torch.optim.Adam checkpoint). */
 int emap_train_stats(const float* edge, const float* true_edge, const float* scalars, int N, float d_scale, float* d_edge,
                      float* stats5, void* stream);
 int emap_train_loss(const float* stats5, float w_over_n, float igr_weight, float igr_ns_weight, float* out2, void* stream);
 int emap_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* step_dev, int64_t n, int64_t n_geo,
-                   float lr_geo, float lr, float beta1, float beta2, float eps, void* stream);
+                   float lr_geo, float lr, double beta1, double beta2, float eps, void* stream);
 /* emap_adam_step_masked : the same with per-element state for the tail [n_geo, n) (the scalars variance / beta / gamma, which the runner
  *                    freezes and un-freezes: runner_udf.py:141-154): tail_mask[j] = 1 trainable / 0 frozen (torch.optim.Adam skips a
  *                    parameter without gradient: no update, no state change), tail_step[j] = that element's own step count
  *                    (bias correction restarts when a parameter is un-frozen, as torch's per-parameter `step`).  Both device
  *                    arrays of n - n_geo floats: no host index tensors, graph-capturable (ABI 6). */
 int emap_adam_step_masked(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* step_dev, int64_t n, int64_t n_geo,
-                          float lr_geo, float lr, float beta1, float beta2, float eps, const float* tail_mask, float* tail_step, void* stream);
+                          float lr_geo, float lr, double beta1, double beta2, float eps, const float* tail_mask, float* tail_step, void* stream);
 
 /* ---- dense-grid extraction (SURVEY par. 8 f2) ----------------------------------------------------
  * emap_null_direction : `_, _, vh = torch.linalg.svd(grad_ld); F.normalize(vh[:, -1, :])` of get_udf_normals_grid /

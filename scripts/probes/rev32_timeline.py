@@ -4,7 +4,9 @@ EMAP_HIP_LIB=emap_amd/lib/tl/libemap_hip.so) and prints, per phase, the median /
 
 Stamps (second tile of workgroups 0..31, every wave): forward layer 2: 0 start tile-pair 0, 1 K-loop issued, 2 epilogue 0 done,
 3 K-loop 1 issued, 4 epilogue 1 done, 5 barrier A passed, 6 exchange written, 7 barrier B passed; (the K32-step stamps of round 3 are gone);
-backward layer 3: 8..15 likewise; 16 tile start, 17 PE done, 18 forward sweep done, 19 last layer, 20 reverse sweep, 21 PE rows, 22 end."""
+backward layer 3: 8..15 likewise; 16 tile start, 17 PE done, 18 forward sweep done, 19 last layer, 20 reverse sweep, 21 PE rows, 22 end;
+round 5 (MX builds): 23 / 24 = mx_finish (block maxima -> scales, the two fp6 conversions per column tile) done in the forward / backward layer.
+usage: rev32_timeline.py [--prec f16x3|f16x3m] [--zero] [--w16]"""
 import ctypes as C, json, os, sys
 import numpy as np
 import torch
@@ -15,7 +17,8 @@ from emap_amd import synthetic, _lib
 
 dev = torch.device("cuda:0")
 kw = dict(d_in=3, d_out=1, d_hidden=256, n_layers=8, skip_in=(4,), multires=10, bias=0.5)
-net = emap_amd.UDFNetwork(scale=1.0, precision="f16x3", **kw)
+PREC = sys.argv[sys.argv.index("--prec") + 1] if "--prec" in sys.argv else "f16x3"
+net = emap_amd.UDFNetwork(scale=1.0, precision=PREC, **kw)
 state = synthetic.make_udf_state(seed=42, pert=0.02, **kw)
 if "--zero" in sys.argv:     # same instruction stream on all-zero operands: what the clock does without data toggling
     state = {k: v * 0 for k, v in state.items()}
@@ -44,13 +47,18 @@ t = np.frombuffer(buf, dtype=np.int64).reshape(32, 4, 64)
 def seg(a, b):
     d = (t[:, :, b] - t[:, :, a]).reshape(-1)
     return {"median": int(np.median(d)), "min": int(d.min()), "max": int(d.max())}
-names = [("fwd K-loop tile-pair 0", 0, 1), ("fwd epilogue 0", 1, 2), ("fwd K-loop 1", 2, 3), ("fwd epilogue 1", 3, 4), ("fwd wait barrier A", 4, 5),
+mxf = bool((t[:, :, 23] > 0).all())      # the forward layer published through publish6 (f16x3m)
+mxb = bool((t[:, :, 24] > 0).all())
+names = [("fwd K-loop tile-pair 0", 0, 1), ("fwd epilogue 0", 1, 2), ("fwd K-loop 1", 2, 3), ("fwd epilogue 1", 3, 4)] + \
+        ([("fwd mx_finish (scales + fp6 conversions)", 4, 23), ("fwd wait barrier A", 23, 5)] if mxf else [("fwd wait barrier A", 4, 5)]) + [
          ("fwd exchange writes", 5, 6), ("fwd wait barrier B", 6, 7), ("fwd layer total", 0, 7),
-         ("bwd K-loop 0", 8, 9), ("bwd epilogue 0", 9, 10), ("bwd K-loop 1", 10, 11), ("bwd epilogue 1", 11, 12), ("bwd wait barrier A", 12, 13),
+         ("bwd K-loop 0", 8, 9), ("bwd epilogue 0", 9, 10), ("bwd K-loop 1", 10, 11), ("bwd epilogue 1", 11, 12)] + \
+        ([("bwd mx_finish (scales + fp6 conversions)", 12, 24), ("bwd wait barrier A", 24, 13)] if mxb else [("bwd wait barrier A", 12, 13)]) + [
          ("bwd exchange writes", 13, 14), ("bwd wait barrier B", 14, 15), ("bwd layer total", 8, 15),
          ("PE block", 16, 17), ("forward sweep", 17, 18), ("last layer", 18, 19), ("reverse sweep", 19, 20), ("layer-0 PE rows", 20, 21), ("reduction + output", 21, 22),
          ("tile total", 16, 22)]
-out = {k: seg(a, b) for k, a, b in names}
+out = {"precision": PREC}
+out.update({k: seg(a, b) for k, a, b in names})
 rt = (t[:, :, 33] - t[:, :, 32]).reshape(-1).astype(np.float64)          # s_memrealtime: constant 100 MHz
 ck = (t[:, :, 22] - t[:, :, 16]).reshape(-1).astype(np.float64)
 out["s_memtime ticks per s_memrealtime tick (x 100 MHz = tick rate)"] = float(np.median(ck / rt))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Host-side profile of the drop-in training step (bench.train_dropin_key's step): where the time between the GPU kernels goes.
-usage: python scripts/profile_dropin_step.py [--fused] > out.txt      (needs a GPU)"""
+usage: python scripts/profile_dropin_step.py [--fused | --patched] > out.txt      (needs a GPU)"""
 import cProfile
 import io
 import os
@@ -16,6 +16,7 @@ import bench  # noqa: E402
 
 def main():
     fused = "--fused" in sys.argv
+    patched = "--patched" in sys.argv
     dev = torch.device("cuda", 0)
     grabbed = {}
     orig = bench._timed
@@ -25,7 +26,7 @@ def main():
         return orig(step, steps, warmup)
 
     bench._timed = grab
-    r = bench.train_dropin_key(dev, "f16x3", 512, steps=20, warmup=10, fused_adam=fused)
+    r = bench.train_dropin_key(dev, "f16x3", 512, steps=20, warmup=10, fused_adam=fused, patched=patched)
     print("ms_per_step", r["ms_per_step"], "median", r["ms_per_step_median"])
     step = grabbed["step"]
     # (1) the GPU work of one step if the host never waited: enqueue 20 steps' worth is impossible (the step syncs), so time the

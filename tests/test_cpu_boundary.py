@@ -296,3 +296,119 @@ def test_graft_entry_verifies_the_prebuilt_library():
     (the compile itself - minutes - is the driver's check; this is the part that can silently go stale)."""
     import __graft_entry__ as g
     g.verify_library()
+
+
+def test_host_scalar_answers_host_reads_without_touching_the_tensor():
+    """emap_amd.host_scalars.HostScalar (round 5): item / float / format / comparisons with python numbers / mean() of a constant tensor
+    come from the host mirror (after waiting for ITS event only); every torch op still sees the tensor, and autograd stays attached."""
+    import torch
+    from emap_amd.host_scalars import HostScalar
+
+    class Ev:
+        n = 0
+
+        def synchronize(self):
+            Ev.n += 1
+
+    host = torch.tensor([0.25, 7.5, 2.0, 0.0])
+    p = torch.nn.Parameter(torch.tensor([0.5]))
+    dev_val = (p * 0.5).expand(6, 1)                      # "variance": one number expanded over N*S rows, differentiable
+    v = HostScalar.wrap(dev_val, host, 0, Ev())
+    b = HostScalar.wrap(torch.tensor([7.5]), host, 1, Ev())
+    assert isinstance(v, torch.Tensor) and v.shape == (6, 1)
+    m = v.mean()
+    assert isinstance(m, HostScalar) and m.dim() == 0 and m.item() == 0.25 and float(m) == 0.25
+    c = m < 2 * b.item()
+    assert isinstance(c, torch.Tensor) and c.device.type == "cpu" and bool(c) is True
+    assert bool(m < 0.01) is False and bool(m >= 0.25) and "{:.2f}".format(m) == "0.25" and b.tolist() == [7.5]
+    assert Ev.n >= 5                                          # every host read waited for the mirror's event
+    # torch ops: plain tensors out, values from the DEVICE tensor, autograd attached
+    y = (v * 2.0).sum()
+    assert type(y) is torch.Tensor
+    y.backward()
+    assert torch.allclose(p.grad, torch.tensor([6.0]))
+    assert torch.equal(v.mean(dim=0), dev_val.mean(dim=0)) and not isinstance(v.mean(dim=0), HostScalar)
+    t = torch.tensor([1.0, 2.0]).as_subclass(HostScalar)      # no mirror attached: behaves like the tensor it is
+    assert t.mean().item() == 1.5 and bool((t < 1.5)[0])
+
+
+def test_dropin_train_wrapper_on_a_runner_shaped_class(monkeypatch):
+    """emap_amd.dropin.patch_runner(train=True): Runner_UDF.train_udf runs unmodified with the renderer's two fast-path switches on, the
+    module's SummaryWriter wrapped (and restored), pending scalars flushed at the end; a CPU runner keeps its torch.optim.Adam."""
+    import sys, types
+    import torch
+    from emap_amd import dropin
+    rows, seen = [], {}
+
+    class SummaryWriter:
+        def __init__(self, log_dir=None):
+            self.log_dir = log_dir
+
+        def add_scalar(self, tag, value, step=None):
+            rows.append((tag, float(value), step))
+
+        def close(self):
+            seen["closed"] = True
+
+    class Renderer:
+        device = "cpu"
+        host_mirror_scalars = False
+        direct_param_grads = False
+
+    class Runner_UDF:
+        report_freq = 2
+
+        def __init__(self):
+            self.renderer = Renderer()
+            self.optimizer = torch.optim.Adam([torch.nn.Parameter(torch.zeros(2))], lr=1e-3)
+
+        def validate(self, idx=-1):
+            return idx
+
+        def train_udf(self):
+            seen["flags"] = (self.renderer.host_mirror_scalars, self.renderer.direct_param_grads)
+            self.writer = sys.modules[type(self).__module__].SummaryWriter(log_dir="x")
+            seen["writer"] = type(self.writer).__name__
+            for it in range(1, 4):
+                self.writer.add_scalar("Loss/loss", torch.tensor(float(it)), it)      # host tensors pass straight through
+                self.writer.add_scalar("Sta/beta", 0.5, it)
+            return "done"
+
+    mod = types.ModuleType("src.runner.runner_udf")
+    mod.Runner_UDF, mod.SummaryWriter = Runner_UDF, SummaryWriter
+    Runner_UDF.__module__ = "src.runner.runner_udf"
+    monkeypatch.setitem(sys.modules, "src.runner.runner_udf", mod)
+    assert dropin.patch_runner(train=True) and not dropin.patch_runner(train=True)
+    r = Runner_UDF()
+    assert r.train_udf() == "done"
+    assert seen["flags"] == (True, True) and seen["writer"] == "DeferredScalarWriter" and r.writer.log_dir == "x"
+    assert mod.SummaryWriter is SummaryWriter                                         # restored
+    assert (r.renderer.host_mirror_scalars, r.renderer.direct_param_grads) == (False, False)
+    assert type(r.optimizer) is torch.optim.Adam                                      # not a CUDA runner: the optimizer is left alone
+    assert rows == [(t, v, s) for s in (1, 2, 3) for t, v in (("Loss/loss", float(s)), ("Sta/beta", 0.5))]
+    r.writer.close()
+    assert seen.get("closed")
+
+
+def test_masked_selection_reduces_without_materialising():
+    """host_scalars.LazyMaskable / MaskedSelection: the runner's ``udf.min(dim=1)[0][mask[:, 0] > 0.5].mean()`` (runner_udf.py:126) evaluates
+    to torch's value without boolean-mask indexing (whose nonzero is a device synchronisation); other uses materialise the real tensor."""
+    import torch
+    from emap_amd.host_scalars import LazyMaskable, MaskedSelection
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(37, 9, generator=g)
+    m = torch.rand(37, 1, generator=g)
+    ref = x.min(dim=1)[0][m[:, 0] > 0.5].mean()
+    u = x.clone().as_subclass(LazyMaskable)
+    sel = u.min(dim=1)[0][m[:, 0] > 0.5]
+    assert isinstance(sel, MaskedSelection) and sel._t is None
+    got = sel.mean()
+    assert type(got) is torch.Tensor and torch.allclose(got, ref, rtol=1e-6) and sel._t is None        # nothing was materialised
+    assert torch.allclose(sel.sum(), x.min(dim=1)[0][m[:, 0] > 0.5].sum(), rtol=1e-6)
+    assert sel.shape == x.min(dim=1)[0][m[:, 0] > 0.5].shape and sel._t is not None                    # any other use: the real selection
+    assert torch.equal(sel.max(), x.min(dim=1)[0][m[:, 0] > 0.5].max())
+    none = u.min(dim=1)[0][m[:, 0] > 2.0].mean()
+    assert torch.isnan(none)                                                                           # empty selection: NaN, like torch
+    assert torch.equal(u[3], x[3]) and torch.equal(u[:, 2], x[:, 2]) and type(u + 1) is torch.Tensor   # ordinary indexing / ops untouched
+    full = x.clone().as_subclass(LazyMaskable)[torch.rand(37, 9, generator=g) > 0.5]
+    assert isinstance(full, MaskedSelection)

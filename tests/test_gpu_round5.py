@@ -107,3 +107,93 @@ def test_fused_adam_loads_a_torch_adam_checkpoint_and_vice_versa():
     _steps([(od, geo_d + tail_d), (ob, geo_b + tail_b)], g3, 2, s0=6)
     for pd_, pb in zip(geo_d + tail_d, geo_b + tail_b):
         assert torch.allclose(pd_, pb, rtol=3e-6, atol=1e-7)
+
+
+# ---------------------------------------------------------------------------------------- the drop-in training step, patched
+def _run_loop(patched, fused, steps=6, rays=128):
+    """bench._RunnerLoop = the body of Runner_UDF.train_udf's loop (runner_udf.py:63-186) on the drop-in classes."""
+    import sys
+    import bench
+    from emap_amd import dropin
+    torch.manual_seed(1234)                       # the jitter draw is the reference's CPU-generator draw
+    rows, reads = [], [0]
+
+    class Rec(bench.SummaryWriter):
+        def add_scalar(self, tag, scalar_value, global_step=None, *a, **k):
+            if isinstance(scalar_value, torch.Tensor) and scalar_value.is_cuda:
+                reads[0] += 1
+            rows.append((tag, float(scalar_value.detach()) if isinstance(scalar_value, torch.Tensor) else float(scalar_value), global_step))
+
+    loop = bench._RunnerLoop(DEV, "f16x3", rays, fused)
+    old = bench.SummaryWriter
+    bench.SummaryWriter = Rec
+    try:
+        train = bench._RunnerLoop.train_udf
+        if patched:
+            train = dropin.train_wrapper(train, sys.modules["bench"])
+        texts = []
+
+        def run(step):
+            for _ in range(steps):
+                step()
+                texts.append(loop.last_loss)
+        train(loop, run)
+    finally:
+        bench.SummaryWriter = old
+    torch.cuda.synchronize()
+    loop.renderer.check_errors()
+    params = torch.cat([p.detach().reshape(-1) for p in list(loop.udf_network.parameters()) + [loop.variance_network_fine.variance,
+                                                                                            loop.beta_network.beta, loop.beta_network.gamma]])
+    return loop, params.cpu(), rows, texts, reads[0]
+
+
+def test_patched_runner_step_takes_the_same_steps_without_the_host_reads():
+    """dropin.train_wrapper: host-mirrored variance / beta / gamma, gradients installed by RenderFn, FusedAdam swapped
+    in for the runner's torch.optim.Adam, deferred tensorboard scalars - and the SAME training run: parameters after 6 steps equal the
+    unpatched loop's with FusedAdam bit for bit (same kernels, same arithmetic), torch.optim.Adam's to its usual 3e-6; the progress text
+    and every tensorboard row (tag, value, step, order) are those of the unpatched loop; no device tensor is read by the writer."""
+    from emap_amd.parallel import FusedAdam
+    l0, p0, rows0, txt0, reads0 = _run_loop(False, True)
+    l1, p1, rows1, txt1, reads1 = _run_loop(True, False)          # starts from torch.optim.Adam: the wrapper swaps it
+    assert isinstance(l1.optimizer, FusedAdam) and reads0 > 0 and reads1 == 0
+    assert torch.equal(p0, p1)
+    assert txt0 == txt1
+    assert [(t_, s) for t_, _, s in rows0] == [(t_, s) for t_, _, s in rows1] and len(rows1) == 6 * 7
+    for (_, a, _), (_, b, _) in zip(rows0, rows1):
+        assert a == b or abs(a - b) <= 1e-6 * max(abs(a), 1e-12)     # "Sta/variance": mean over N*S copies of x vs x itself
+    l2, p2, _, _, _ = _run_loop(False, False)                    # the stock optimizer
+    assert torch.allclose(p1, p2, rtol=3e-5, atol=2e-7)
+    assert (l1.renderer.host_mirror_scalars, l1.renderer.direct_param_grads) == (False, False)      # restored after train_udf
+
+
+def test_direct_param_grads_equal_autograd_accumulated_ones_and_fall_back_when_grads_exist():
+    """RenderFn.backward with direct_param_grads: the parameters' .grad ARE views of one flat buffer (FusedAdam reads it in place) and
+    equal what autograd accumulates on the ordinary path; with gradients already present the ordinary (accumulating) path runs."""
+    import bench
+    outs = {}
+    for direct in (False, True):
+        torch.manual_seed(7)
+        loop = bench._RunnerLoop(DEV, "f16x3", 64, True)
+        loop.renderer.direct_param_grads = direct
+        smp = loop.sampler.gen_random_rays_patches_at(0, 64, importance_sample=True)
+        ps = list(loop.udf_network.parameters()) + [loop.variance_network_fine.variance, loop.beta_network.beta, loop.beta_network.gamma]
+
+        def loss_of():
+            o = loop.renderer.render(smp["rays"]["rays_o"], smp["rays"]["rays_v"], loop.near, loop.far, depth_scale=smp["depth_scale"],
+                                     flip_saturation=0.9, cos_anneal_ratio=1.0, t_rand=torch.zeros(64, 1, device=DEV))
+            return ((o["edge"] - smp["rays"]["edge"]) ** 2).mean() + 0.1 * o["gradient_error"]
+        loss_of().backward()
+        g1 = [p.grad.clone() for p in ps]
+        if direct:
+            base = ps[0].grad.data_ptr()
+            off = 0
+            for p in list(loop.udf_network.parameters()):
+                assert p.grad.data_ptr() == base + 4 * off
+                off += p.numel()
+        loss_of().backward()                       # no zero_grad in between: gradients accumulate
+        g2 = [p.grad.clone() for p in ps]
+        outs[direct] = (g1, g2)
+    for a, b in zip(outs[False][0], outs[True][0]):
+        assert torch.equal(a, b)
+    for a, b, c in zip(outs[True][0], outs[True][1], outs[False][1]):
+        assert torch.equal(b, c) and torch.allclose(b, 2 * a, rtol=1e-6, atol=0)
