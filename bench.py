@@ -70,6 +70,10 @@ def parse():
     ap.add_argument("--precision", default=os.environ.get("EMAP_BENCH_PRECISION", "f16x3"), choices=list(MODE_DTYPE),
                     help="arithmetic of the MLP GEMMs for `value`; f16x3 is the mode that meets the 1e-4 parity gate")
     ap.add_argument("--eikonal-sync", default="exact_lagged", choices=["exact", "exact_lagged", "local"], help="train mode, N > 1 (emap_amd/parallel.py)")
+    ap.add_argument("--allreduce", default="rccl", choices=["rccl", "oneshot"],
+                    help="train mode, N > 1: the gradient bucket's collective - rccl = torch.distributed.all_reduce on --backend; oneshot = "
+                         "emap_amd's peer-to-peer kernel over hipIpc mappings (csrc/allreduce.hip: every rank reads every peer's bucket directly "
+                         "over xGMI, one launch)")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="replay the step from a captured hipGraph (auto: render mode yes - falling back to eager launches if the "
                          "capture fails -, train mode no)")
@@ -473,18 +477,22 @@ def dry_run_nccl():
         print(json.dumps({"dry_run_nccl": "skipped", "reason": f"{n} GPU(s) visible; the RCCL branch needs 2"}), flush=True)
         return 0
     outs = {}
-    for graph in ("off", "on"):
+    # eager and per-phase graphs over RCCL; then the same step with the gradient bucket through the peer-to-peer kernel (--allreduce oneshot)
+    # in both eikonal modes a first scaling run would compare: local (ONE collective per step) and exact_lagged (two)
+    for name, extra in (("eager", ["--graph", "off"]), ("per_phase_graphs", ["--graph", "on"]),
+                        ("oneshot_local", ["--graph", "off", "--allreduce", "oneshot", "--eikonal-sync", "local"]),
+                        ("oneshot_exact_lagged", ["--graph", "off", "--allreduce", "oneshot"])):
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "2", "--mode", "train", "--steps", "3", "--warmup", "1", "--settle-steps", "2",
-               "--graph", graph, "--no-cpu-baseline", "--no-parity"]
+               "--no-cpu-baseline", "--no-parity"] + extra
         try:
             p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
             ln = [x for x in p.stdout.splitlines() if x.startswith("{")]
-            outs[graph] = {"rc": p.returncode, "ms_per_step": (json.loads(ln[-1])["ms_per_step"] if ln else None),
-                           "stderr_tail": p.stderr[-400:] if p.returncode else ""}
+            outs[name] = {"rc": p.returncode, "ms_per_step": (json.loads(ln[-1])["ms_per_step"] if ln else None),
+                          "stderr_tail": p.stderr[-400:] if p.returncode else ""}
         except subprocess.TimeoutExpired:
-            outs[graph] = {"rc": None, "error": "timeout after 600 s"}
+            outs[name] = {"rc": None, "error": "timeout after 600 s"}
     ok = all(o.get("rc") == 0 for o in outs.values())
-    print(json.dumps({"dry_run_nccl": "ok" if ok else "FAILED", "ranks": 2, "eager": outs["off"], "per_phase_graphs": outs["on"]}), flush=True)
+    print(json.dumps({"dry_run_nccl": "ok" if ok else "FAILED", "ranks": 2, **outs}), flush=True)
     return 0 if ok else 1
 
 
@@ -557,7 +565,8 @@ def main():
         # jitters them with a device Philox draw, and takes one optimizer step.  No host->device copy per step.
         import emap_amd
         from emap_amd.parallel import Trainer
-        trainer = Trainer(r, lr_geo=1e-4, lr=5e-4, edge_weight=1.0, igr_weight=0.1, igr_ns_weight=0.0, eikonal_sync=a.eikonal_sync)
+        trainer = Trainer(r, lr_geo=1e-4, lr=5e-4, edge_weight=1.0, igr_weight=0.1, igr_ns_weight=0.0, eikonal_sync=a.eikonal_sync,
+                          allreduce=a.allreduce)
         meta, edges = synthetic.make_scene(n_images=8, H=400, W=400, seed=3)
         sampler = emap_amd.DeviceRaySampler.from_meta(meta, edges, device=dev, seed=1000 + rank)   # every rank draws its own shard
         sampler.set_image_perm(list(range(8)))
@@ -726,6 +735,8 @@ def main():
                                                                + (" whose tail carries every rank's range maxima for the NEXT step" if a.eikonal_sync == "exact_lagged" and world > 1 else "")
                                                                + ")"),
                        "collectives_per_step": (trainer.collectives_per_step if a.mode == "train" else 0),
+                       "eikonal_sync": (a.eikonal_sync if a.mode == "train" else None),
+                       "gradient_allreduce": ((a.allreduce if world > 1 else None) if a.mode == "train" else None),
                        "ranks": world, "backend": (a.backend if world > 1 else None), "rccl_ranks": (world if (world > 1 and a.backend == "nccl") else 0),
                        "devices": ([(i if a.backend == "nccl" else i % torch.cuda.device_count()) for i in range(world)]),
                        "settle_steps": a.settle_steps},
@@ -813,6 +824,9 @@ def main():
             except Exception as e:  # the baseline must never take the GPU line down
                 line["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(line), flush=True)
+    if trainer is not None and getattr(trainer, "_oneshot", None) is not None:
+        trainer._oneshot.check()        # a launch that gave up on a peer must fail the bench, not report a number
+        trainer._oneshot.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -113,6 +113,13 @@ SYMBOLS = {
     "emap_train_loss": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, _P, _P]),
     "emap_adam_step": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_double, C.c_double, C.c_float, _P]),
     "emap_adam_step_masked": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_double, C.c_double, C.c_float, _P, _P, _P]),
+    "emap_ar_local_bytes": (C.c_int, [C.c_int64, C.POINTER(C.c_size_t)]),
+    "emap_ar_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p), _P]),
+    "emap_ar_open": (C.c_int, [_P, C.POINTER(C.c_void_p)]),
+    "emap_ar_close": (C.c_int, [_P]),
+    "emap_ar_free": (C.c_int, [_P]),
+    "emap_ar_allreduce_sum": (C.c_int, [_P, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_size_t, _P]),
+    "emap_ar_error": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "emap_profile_enable": (C.c_int, [C.c_int]),
     "emap_profile_read": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "emap_profile_read_kernel": (C.c_int, [C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]),

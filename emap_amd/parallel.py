@@ -44,6 +44,84 @@ def _world(group=None) -> int:
     return dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
 
 
+class OneShotAllReduce:
+    """SUM all-reduce of a small fp32 bucket by direct peer reads over xGMI (csrc/allreduce.hip; SURVEY.md par. 8e "xGMI note"): every rank
+    reads every other rank's staging buffer through ``hipIpcMemHandle`` mappings and sums in rank order - one launch, one synchronisation,
+    bit-identical results on all ranks; no host work per call (graph-capturable).  The alternative to RCCL's ring for the step's
+    latency-bound 1.85 MB gradient bucket (``Trainer(..., allreduce="oneshot")``, ``bench.py --allreduce oneshot``).
+
+    Construction is collective: the ranks exchange their 64-byte IPC handles through ``torch.distributed`` (any backend, gloo included -
+    the ranks may even share one GPU, which is how the one-GPU tests run it).  One node only (IPC handles do not cross hosts)."""
+
+    def __init__(self, n_floats: int, device, group=None):
+        import ctypes as C
+        from . import _lib
+        assert dist.is_available() and dist.is_initialized(), "OneShotAllReduce needs an initialised process group (for the handle exchange)"
+        self.group, self.device = group, torch.device(device)
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.n_floats = int(n_floats)
+        L = _lib.lib()
+        nb = C.c_size_t()
+        _lib.check(L.emap_ar_local_bytes(self.n_floats, C.byref(nb)), "ar_local_bytes")
+        self.region_bytes = nb.value
+        self._own = C.c_void_p()
+        handle = (C.c_ubyte * 64)()
+        with torch.cuda.device(self.device):
+            _lib.check(L.emap_ar_alloc(self.region_bytes, C.byref(self._own), handle), "ar_alloc")
+        handles = [None] * self.world
+        dist.all_gather_object(handles, bytes(handle), group=group)
+        self._peers = []
+        regions = (C.c_void_p * self.world)()
+        with torch.cuda.device(self.device):
+            for r, h in enumerate(handles):
+                if r == self.rank:
+                    regions[r] = self._own.value
+                    continue
+                p = C.c_void_p()
+                _lib.check(L.emap_ar_open((C.c_ubyte * 64).from_buffer_copy(h), C.byref(p)), "ar_open")
+                self._peers.append(p)
+                regions[r] = p.value
+        self._regions = regions
+        dist.barrier(group=group)               # every rank has mapped every region before the first launch touches one
+
+    def __call__(self, t: torch.Tensor) -> torch.Tensor:
+        """In place: t <- sum over the ranks of t.  fp32, contiguous, on this device, at most n_floats elements; every rank must call it
+        with the same number of elements, in the same order."""
+        from . import _lib
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() <= self.n_floats
+        with torch.cuda.device(t.device):
+            _lib.check(_lib.lib().emap_ar_allreduce_sum(_lib.ptr(t), t.numel(), self.rank, self.world, self._regions, self.region_bytes,
+                                                        _lib.stream_ptr(t.device)), "ar_allreduce_sum")
+        return t
+
+    def check(self):
+        """Raise if a launch gave up waiting for a peer (host read: synchronises)."""
+        import ctypes as C
+        from . import _lib
+        e = C.c_int()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().emap_ar_error(self._own, C.byref(e)), "ar_error")
+        if e.value:
+            raise RuntimeError("OneShotAllReduce: a peer's buffer did not arrive within the kernel's time-out (a rank died or the ranks do "
+                               "not call the collective in lock step)")
+
+    def close(self):
+        from . import _lib
+        L = _lib.lib()
+        if getattr(self, "_own", None) is None:
+            return
+        try:
+            torch.cuda.synchronize(self.device)
+            dist.barrier(group=self.group)       # nobody unmaps while a peer may still read
+        except Exception:
+            pass
+        with torch.cuda.device(self.device):
+            for p in self._peers:
+                L.emap_ar_close(p)
+            L.emap_ar_free(self._own)
+        self._peers, self._own = [], None
+
+
 class FlatParams:
     """Re-homes `params` as views of ONE flat fp32 buffer (and their .grad as views of one flat gradient buffer), so that a
     gradient all-reduce and an optimizer step touch one tensor instead of one per parameter."""
@@ -98,7 +176,7 @@ class Trainer:
 
     def __init__(self, renderer, lr_geo: float = 1e-4, lr: float = 5e-4, edge_weight: float = 1.0, igr_weight: float = 0.1,
                  igr_ns_weight: float = 0.0, group=None, eikonal_sync: str = "exact", fused_adam: Optional[bool] = None,
-                 native_tail: Optional[bool] = None):
+                 native_tail: Optional[bool] = None, allreduce: str = "rccl"):
         assert eikonal_sync in ("exact", "exact_lagged", "local")
         # only "exact_lagged" uses the rank-indexed maxima slots of the bucket's tail: "exact" / "local" run on any number of ranks
         assert eikonal_sync != "exact_lagged" or _world(group) <= self.MAX_RANKS, \
@@ -158,6 +236,14 @@ class Trainer:
         self._igr_ns = torch.tensor([self.igr_ns_weight * k], device=dev)
         self._idx = torch.tensor([4, 6, 3, 5], device=dev)
         self.last_stats = None
+        # the gradient bucket's collective: "rccl" = torch.distributed.all_reduce on the group's backend (RCCL / gloo);
+        # "oneshot" = direct peer reads over hipIpc mappings (OneShotAllReduce; one node, GPU only).  The 20-byte statistics / 8-byte
+        # maxima exchanges of the exact modes stay on torch.distributed either way.
+        assert allreduce in ("rccl", "oneshot")
+        self.allreduce = allreduce
+        self._oneshot = None
+        if allreduce == "oneshot" and _world(group) > 1:
+            self._oneshot = OneShotAllReduce(self.flat.grad.numel(), dev, group)
 
     # ---- the three device stages; the CPU tests substitute oracle implementations for the two HIP ones ----
     def _forward(self, rays):
@@ -297,7 +383,7 @@ class Trainer:
         if _world(self.group) == 1:
             return []
         ar = lambda t, op: (lambda S: dist.all_reduce(t(S), op=op, group=self.group))
-        grad = ar(lambda S: self.flat.grad, dist.ReduceOp.SUM)
+        grad = ar(lambda S: self.flat.grad, dist.ReduceOp.SUM) if self._oneshot is None else (lambda S: self._oneshot(self.flat.grad))
         if self.eikonal_sync == "local":
             return [(2, grad)]
         stats = (0, ar(lambda S: self._stats, dist.ReduceOp.SUM))

@@ -356,6 +356,27 @@ int emap_profile_read_kernel(int which, float* total_ms_host, int* launches_host
  * 0 if no such launch was recorded.  (The dominant kernel runs at the package power cap on real data: DESIGN.md par. 5.) */
 int emap_profile_read_clock(int which, float* mhz_host);
 
+/* ---- one-shot peer-to-peer all-reduce of the gradient bucket (SURVEY par. 8e "xGMI note"; csrc/allreduce.hip; ABI 7) ----------------
+ * The data-parallel step's single collective (emap_amd/parallel.py; the reference has none: EMAP is single-GPU, runner_udf.py:166-168)
+ * is a 1.85 MB SUM: latency-bound.  Instead of RCCL's ring (2 (R-1) dependent steps) every rank reads every other rank's bucket
+ * directly over the xGMI mesh and sums in rank order (bit-identical on all ranks), one synchronisation, one launch, no host work.
+ *   emap_ar_local_bytes   : size of a rank's REGION for buckets of up to n_floats: [256 B control][2 x staging]
+ *   emap_ar_alloc         : allocates + zeroes a region (uncached device memory) and returns its 64-byte hipIpcMemHandle; the caller
+ *                           exchanges the handles of all ranks on the host (torch.distributed all_gather_object, any backend)
+ *   emap_ar_open / _close : map / unmap a peer's region from its handle (hipIpcOpenMemHandle; needs HSA_ENABLE_IPC_MODE_LEGACY=0 here)
+ *   emap_ar_allreduce_sum : data[0..n) <- sum over ranks, in place; regions_host = HOST array of `world` device pointers, entry r = the
+ *                           region of rank r as mapped into THIS process (entry `rank` = the own region).  Every rank calls it in lock
+ *                           step with the same n.  Graph-capturable (the step counter lives in the region).  A peer that does not
+ *                           show up within ~2 s sets the error word instead of hanging the device.
+ *   emap_ar_error         : host read of that error word (synchronises). */
+int emap_ar_local_bytes(int64_t n_floats, size_t* bytes);
+int emap_ar_alloc(size_t bytes, void** region, void* ipc_handle64);
+int emap_ar_open(const void* ipc_handle64, void** peer_region);
+int emap_ar_close(void* peer_region);
+int emap_ar_free(void* region);
+int emap_ar_allreduce_sum(float* data, int64_t n, int rank, int world, void* const* regions_host, size_t region_bytes, void* stream);
+int emap_ar_error(void* region, int* error_host);
+
 /* host-only: torch.linspace(start, end, steps) in fp32, the grid of sample_pdf's u / the coarse z_vals */
 void emap_linspace_host(float start, float end, int steps, float* out_host);
 

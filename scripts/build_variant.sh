@@ -18,7 +18,7 @@ for u in $UNITS; do
 done
 for p in "${pids[@]}"; do wait $p; done
 OBJS=""
-for u in udf_mlp udf_mlp_bf16 udf_mlp_bf16x3 udf_mlp_f16 udf_mlp_f16x3 sampler extraction wgrad rays train api; do
+for u in udf_mlp udf_mlp_bf16 udf_mlp_bf16x3 udf_mlp_f16 udf_mlp_f16x3 sampler extraction wgrad rays train allreduce api; do
   if [[ " $UNITS " == *" $u "* ]]; then OBJS="$OBJS $OUT/$u.o"; else OBJS="$OBJS $LIB/$u.o"; fi
 done
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libemap_hip.so" $OBJS

@@ -26,7 +26,7 @@ def _need(n):
         pytest.skip(f"needs {n} GPUs, {torch.cuda.device_count() if torch.cuda.is_available() else 0} visible")
 
 
-def _rank_step(rank, world, port, n_global, sync, q, backend="nccl", capture=False):
+def _rank_step(rank, world, port, n_global, sync, q, backend="nccl", capture=False, allreduce="rccl"):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
     import emap_amd
@@ -54,7 +54,7 @@ def _rank_step(rank, world, port, n_global, sync, q, backend="nccl", capture=Fal
     rays = [shard(t_, rank, world).to(dev) for t_ in synthetic.make_rays(n_global, seed=77)]
     te = shard(synthetic.make_true_edge(n_global, seed=78), rank, world).to(dev)
     tr = shard(synthetic.make_t_rand(n_global, seed=79), rank, world).to(dev)
-    t = Trainer(r, lr_geo=1e-3, lr=5e-3, igr_weight=0.1, igr_ns_weight=0.05, eikonal_sync=sync)
+    t = Trainer(r, lr_geo=1e-3, lr=5e-3, igr_weight=0.1, igr_ns_weight=0.05, eikonal_sync=sync, allreduce=allreduce)
     batch = dict(zip(("rays_o", "rays_d", "near", "far", "depth_scale"), rays))
     batch.update(cos_anneal_ratio=1.0, flip_saturation=0.9, t_rand=tr)
     p0 = t.flat.data.detach().cpu().numpy().copy()
@@ -81,17 +81,21 @@ def _rank_step(rank, world, port, n_global, sync, q, backend="nccl", capture=Fal
     stats = step(batch, te, n_rays_global=n_global)
     torch.cuda.synchronize()
     r.check_errors()
+    if t._oneshot is not None:
+        t._oneshot.check()
     q.put((rank, stats.cpu().numpy(), t.flat.data.cpu().numpy(), t.flat.grad[:t.flat.numel].cpu().numpy(), p0, stats1, grad1))
     if world > 1:
+        if t._oneshot is not None:
+            t._oneshot.close()
         dist.barrier()
         dist.destroy_process_group()
 
 
-def _launch(world, n_global, sync, backend="nccl", capture=False):
+def _launch(world, n_global, sync, backend="nccl", capture=False, allreduce="rccl"):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_rank_step, args=(r, world, port, n_global, sync, q, backend, capture)) for r in range(world)]
+    procs = [ctx.Process(target=_rank_step, args=(r, world, port, n_global, sync, q, backend, capture, allreduce)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=600) for _ in range(world)]
@@ -234,3 +238,91 @@ def test_dry_run_nccl_self_check_reports():
         assert out.returncode == 0 and line["dry_run_nccl"] == "skipped"
     else:
         assert out.returncode == 0 and line["dry_run_nccl"] == "ok", (line, out.stderr[-2000:])
+
+
+# ---------------------------------------------------------------------------------------- one-shot peer-to-peer all-reduce (round 5)
+def _rank_oneshot(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    from emap_amd.parallel import OneShotAllReduce
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    n = 462985 + 8                                        # the d8 w256 gradient bucket with its statistics tail: NOT a multiple of 4
+    ar = OneShotAllReduce(n, dev)
+    gen = torch.Generator().manual_seed(100 + rank)
+    ok, worst = True, 0.0
+    for it in range(25):                                  # back to back: the double-buffered staging, the step counter
+        m = n if it % 3 else n - 5 - it                   # shorter messages in between (all ranks the same length)
+        x = torch.randn(m, generator=gen).to(dev)
+        ref = x.clone()
+        dist.all_reduce(ref, op=dist.ReduceOp.SUM)        # gloo, through the host
+        y = ar(x.clone())
+        torch.cuda.synchronize()
+        if world == 2:
+            ok = ok and bool(torch.equal(y, ref))         # a + b is the same number in either order
+        worst = max(worst, float((y - ref).abs().max() / ref.abs().max()))
+        g = [torch.empty_like(y) for _ in range(world)]
+        dist.all_gather(g, y)
+        ok = ok and all(bool(torch.equal(g[0], t_)) for t_ in g)      # every rank holds the SAME bits (sum in rank order)
+    ar.check()
+    # a captured launch replays (the step counter lives in the region, nothing of the call is host state)
+    xs = torch.randn(n, generator=gen).to(dev)
+    buf = xs.clone()
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        ar(buf)
+    torch.cuda.current_stream(dev).wait_stream(side)
+    dist.barrier()
+    graph = torch.cuda.CUDAGraph()
+    buf.copy_(xs)
+    with torch.cuda.graph(graph):
+        ar(buf)
+    for _ in range(3):
+        buf.copy_(xs)
+        graph.replay()
+        torch.cuda.synchronize()
+        ref = xs.clone()
+        dist.all_reduce(ref, op=dist.ReduceOp.SUM)
+        worst = max(worst, float((buf - ref).abs().max() / ref.abs().max()))
+    ar.check()
+    q.put((rank, ok, worst))
+    ar.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [2, 3])
+def test_oneshot_allreduce_between_ranks_sharing_one_gpu(world):
+    """csrc/allreduce.hip through OneShotAllReduce: `world` processes on GPU 0 map each other's staging regions through hipIpcMemHandle
+    and sum the 1.85 MB gradient bucket by direct reads - against gloo's all-reduce of the same tensors (bit-equal for 2 ranks, 1e-6 for
+    3: another summation order), bit-identical across the ranks, ragged lengths, 25 launches back to back, and from a captured graph."""
+    _need(1)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_oneshot, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, ok, worst in res:
+        assert ok and worst <= 1e-6, (rank, ok, worst)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("sync", ["local", "exact"])
+def test_trainer_with_the_oneshot_allreduce_takes_the_gloo_steps(sync):
+    """Trainer(allreduce="oneshot") on 2 ranks sharing GPU 0: the gradient bucket travels through the peer-to-peer kernel, everything else as
+    before - same statistics, gradients and parameters as the run whose bucket goes through gloo (2 ranks: a + b in either order), bit for bit."""
+    _need(1)
+    ref = _launch(2, 256, sync, "gloo")
+    one = _launch(2, 256, sync, "gloo", allreduce="oneshot")
+    for a, b in zip(ref, one):
+        assert np.array_equal(a[5], b[5]) and np.array_equal(a[6], b[6])      # step 1: statistics, gradient
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])      # step 2: statistics, parameters
