@@ -48,6 +48,7 @@ A_TRAIN = 6311360         # ... of a training step
 MODE_DTYPE = {
     "f16x3": "f16x3 (split-fp16 MFMA, 3 passes, fp32 accumulate)",
     "f16x3m": "f16x3m (f16x3 with MX-fp6 cross terms in the forward sweep of the value+gradient pass too; gradient error 6.2e-5 of the 1e-4 gate)",
+    "f16x3e": "f16x3e (f16x3 with f16 cross terms in both sweeps of the value+gradient pass - no MX fp6; gradient error 1.5e-5 of the 1e-4 gate)",
     "bf16x3": "bf16x3 (split-bf16 MFMA, 3 passes, fp32 accumulate)",
     "f16": "f16 (single-pass fp16 MFMA, fp32 accumulate)",
     "bf16": "bf16 (single-pass bf16 MFMA, fp32 accumulate)",
@@ -711,7 +712,7 @@ def main():
             # dominant kernel: the value+grad MLP launch over rays*S points; algorithmic work = value + reverse-mode input
             # gradient = 2F per point (SURVEY par. 8d)
             flops_launch = rays * S * 2 * F_POINT / launches_per_step
-            rev = rays * S >= (10240 if a.precision in ("f16x3", "f16x3m", "bf16x3") else 16384)
+            rev = rays * S >= (10240 if a.precision in ("f16x3", "f16x3m", "f16x3e", "bf16x3") else 16384)
             dominant = (f"udf_mlp_rev32_kernel<256,{a.precision}>" if rev else f"udf_mlp_fs2_kernel<256,{a.precision},4,grad>") + " (final value+grad pass)"
             alg = A_FWD
             metric = "ray-samples/sec (UDF MLP + composite)"

@@ -19,7 +19,8 @@ PREC_BF16X3 = 1
 PREC_F16 = 2
 PREC_F16X3 = 3
 PREC_F16X3M = 4    # f16x3 with MX-fp6 cross terms in the forward sweep of the value+gradient pass too (include/emap_hip.h)
-PRECISIONS = {"bf16": PREC_BF16, "bf16x3": PREC_BF16X3, "f16": PREC_F16, "f16x3": PREC_F16X3, "f16x3m": PREC_F16X3M}
+PREC_F16X3E = 5    # f16x3 with f16 cross terms in both sweeps of the value+gradient pass (no MX fp6): the wider-margin mode
+PRECISIONS = {"bf16": PREC_BF16, "bf16x3": PREC_BF16X3, "f16": PREC_F16, "f16x3": PREC_F16X3, "f16x3m": PREC_F16X3M, "f16x3e": PREC_F16X3E}
 UDF_TYPES = {"abs": 0, "square": 1, "sdf": 2}
 MAX_LIN = 12
 ABI_VERSION = 7

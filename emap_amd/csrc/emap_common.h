@@ -60,6 +60,7 @@ struct NetLayout {
     int32_t bias_off_bytes, rowscale_off_bytes, frag_off_bytes;
     int32_t is_f16;
     int32_t mx_fwd;            // EMAP_PREC_F16X3M: the forward 32x32 section (r32) in the mixed MX layout too
+    int32_t mx_bwd;            // 0 = EMAP_PREC_F16X3E: the transposed 32x32 section in plain f16 hi / lo fragments (f16 cross terms in the reverse sweep)
     // transposed section (reverse-mode d(udf)/dx, udf_mlp_rev_kernel): W_l^T fragments for the backward GEMMs
     //   t_off[l]   first fragment of layer l's hidden-row block  [row pair][K-step over out features][t][part], l >= 1
     //   tpe_off[l] first fragment of layer l's PE-row block      [pe pair 0..1][K-step][t][part], l in {0, skip_l}
@@ -78,7 +79,7 @@ struct NetLayout {
 #ifndef EMAP_REV_MX6
 #define EMAP_REV_MX6 1      // 0: f16 cross terms in the backward GEMMs too (A/B builds: compile udf_mlp AND udf_mlp_f16x3 with the flag)
 #endif
-__host__ __device__ inline bool r32_t_mixed(const NetLayout& L) { return EMAP_REV_MX6 && L.is_f16 && L.nparts == 2 && L.H == 256; }
+__host__ __device__ inline bool r32_t_mixed(const NetLayout& L) { return EMAP_REV_MX6 && L.mx_bwd && L.is_f16 && L.nparts == 2 && L.H == 256; }
 // The same for the FORWARD sweep of that kernel (udf_mlp.hip:pack32_body writes the mixed layout too): precision mode EMAP_PREC_F16X3M.
 __host__ __device__ inline bool r32_mixed(const NetLayout& L) { return L.mx_fwd && r32_t_mixed(L); }
 // fixed MX scales of the positional-encoding block (|sin|, |cos| <= 1, raw coordinates up to 1.875 exactly): 2^-2 for the hi parts,

@@ -20,7 +20,7 @@ long long* prof_clk_here() {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-__host__ __device__ constexpr bool prec_is_f16(int mode) { return mode == EMAP_PREC_F16 || mode == EMAP_PREC_F16X3 || mode == EMAP_PREC_F16X3M; }
+__host__ __device__ constexpr bool prec_is_f16(int mode) { return mode == EMAP_PREC_F16 || mode == EMAP_PREC_F16X3 || mode == EMAP_PREC_F16X3M || mode == EMAP_PREC_F16X3E; }
 __host__ __device__ constexpr int prec_nparts(int mode) { return (mode == EMAP_PREC_BF16 || mode == EMAP_PREC_F16) ? 1 : 2; }
 
 // ---------------------------------------------------------------------------------------------
@@ -417,7 +417,7 @@ int build_layout(const EmapNetConfig* cfg, int prec, NetLayout* L) {
     if (cfg->n_lin < 2 || cfg->n_lin > EMAP_MAX_LIN) { set_error("n_lin out of range (%d)", cfg->n_lin); return EMAP_E_INVALID; }
     if (cfg->multires < 0 || cfg->multires > 10) { set_error("multires must be in 0..10 (got %d)", cfg->multires); return EMAP_E_INVALID; }   // 0: raw coordinates only (udf_model.py:26-29)
     if (cfg->d_out != 1) { set_error("d_out must be 1 (got %d): feature outputs are not on the hot path", cfg->d_out); return EMAP_E_INVALID; }
-    if (prec < EMAP_PREC_BF16 || prec > EMAP_PREC_F16X3M) { set_error("unknown precision mode %d", prec); return EMAP_E_INVALID; }
+    if (prec < EMAP_PREC_BF16 || prec > EMAP_PREC_F16X3E) { set_error("unknown precision mode %d", prec); return EMAP_E_INVALID; }
     if (prec == EMAP_PREC_F16X3M && (cfg->d_hidden != 256 || !EMAP_REV_MX6)) {
         set_error("precision f16x3m (MX fp6 cross terms in the forward sweep) needs d_hidden = 256 (got %d)", cfg->d_hidden);
         return EMAP_E_INVALID;
@@ -428,6 +428,7 @@ int build_layout(const EmapNetConfig* cfg, int prec, NetLayout* L) {
     L->H = H; L->n_lin = cfg->n_lin; L->skip_l = cfg->skip_l; L->multires = cfg->multires;
     L->d0 = 3 + 6 * cfg->multires; L->nparts = prec_nparts(prec); L->is_f16 = prec_is_f16(prec) ? 1 : 0;
     L->mx_fwd = (prec == EMAP_PREC_F16X3M) ? 1 : 0;
+    L->mx_bwd = (prec == EMAP_PREC_F16X3E) ? 0 : 1;
     L->udf_type = cfg->udf_type; L->scale = cfg->scale;
     int frag = 0, chunks = 0;
     for (int l = 0; l < cfg->n_lin; ++l) {
@@ -531,7 +532,7 @@ int set_grad_mode(int mode) { return g_grad_mode.exchange((mode == 0 || mode == 
 static int mlp_variant(const NetLayout& L, int prec, int64_t P, bool grad) {
     // reverse mode halves the MFMA work of a grad launch but a tile is two dependent sweeps: it wins once most CUs have a
     // workgroup (measured crossover: the split modes between 8k and 12k points, single-pass modes at 16k).
-    const int64_t rev_min = (prec == EMAP_PREC_F16X3 || prec == EMAP_PREC_F16X3M || prec == EMAP_PREC_BF16X3) ? 10240 : 16384;
+    const int64_t rev_min = (prec == EMAP_PREC_F16X3 || prec == EMAP_PREC_F16X3M || prec == EMAP_PREC_F16X3E || prec == EMAP_PREC_BF16X3) ? 10240 : 16384;
     const int gm = g_grad_mode.load(std::memory_order_relaxed);
     if (grad && L.has_rev && gm != 0 && (P >= rev_min || gm == 1)) return 3;
     return 2;
@@ -547,6 +548,7 @@ int launch_mlp(const NetLayout& L, const void* packed, int prec, const PointSour
         case EMAP_PREC_BF16X3: return launch_mlp_bf16x3(L, packed, src, P, udf, grad3, st, v, err_flags, scratch);
         case EMAP_PREC_F16: return launch_mlp_f16(L, packed, src, P, udf, grad3, st, v, err_flags, scratch);
         case EMAP_PREC_F16X3:
+        case EMAP_PREC_F16X3E:
         case EMAP_PREC_F16X3M: return launch_mlp_f16x3(L, packed, src, P, udf, grad3, st, v, err_flags, scratch);   // L.mx_fwd selects the kernel
     }
     set_error("unknown precision mode %d", prec);

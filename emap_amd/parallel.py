@@ -339,7 +339,11 @@ class Trainer:
             rank = dist.get_rank(self.group)
             tail[2 * rank:2 * rank + 2] = cur
             if self._lag_valid:
-                cur.copy_(torch.maximum(self._lag * 4.0, cur))
+                # scale = 4 x last step's GLOBAL maxima, clamped to [own maxima, 16 x own maxima]: the lower clamp keeps fp16 from
+                # overflowing when the gradients GREW more than 4 x in one step, the upper one from flushing small adjoints when they
+                # SHRANK more than 4 x (a stale scale 1000 x too large leaves fp16 three binades).  Inside the clamp every rank
+                # uses the same number; at a clamp the ranks differ in rounding for that step only.
+                cur.copy_(torch.minimum(torch.maximum(self._lag * 4.0, cur), cur * 16.0))
 
     def _maxima_tail(self):
         n = self.flat.numel + self.N_STATS

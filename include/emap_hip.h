@@ -50,6 +50,10 @@ extern "C" {
                                    reverse sweep has them in every split-fp16 build): d_hidden = 256 only; the kernel ~10 % faster,
                                    grad_x 6.2e-5 instead of 3.0e-5 of the 1e-4 gate (DESIGN.md par. 6c); every other kernel = F16X3 */
 
+#define EMAP_PREC_F16X3E 5      /* EMAP_PREC_F16X3 with f16 cross terms in BOTH sweeps of the value+gradient pass (no MX fp6 anywhere): the round-3
+                                   arithmetic - grad_x 1.5e-5 (max-normalised) / 7.7e-3 (element-wise p99.9) instead of 3.0e-5 / 1.2e-2, the kernel
+                                   ~12 % slower (ABI 7; profiles/r05_elementwise_attribution.txt) */
+
 /* udf_type (udf_model.py:82-88) */
 #define EMAP_UDF_ABS 0
 #define EMAP_UDF_SQUARE 1

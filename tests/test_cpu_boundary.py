@@ -47,6 +47,8 @@ def test_abi_version_and_error_text():
     # skip layer) + 2 PE row pairs for layer 0 and the skip layer, each x (H/32 K-steps) x 2 tiles x parts
     (256, 9, 10, 0, 8 * 4 + 5 * 8 * 16 + 7 * 16 + 8 * 20 + 16, 6 * 8 * 16 + 7 * 16 + 2 * 2 * 16),
     (256, 9, 10, 1, 2 * (8 * 4 + 5 * 8 * 16 + 7 * 16 + 8 * 20 + 16), 2 * (6 * 8 * 16 + 7 * 16 + 2 * 2 * 16)),
+    # f16x3e (5): f16x3's fragment counts (its transposed 32x32 section in plain hi / lo fragments instead of the mixed MX layout: same bytes)
+    (256, 9, 10, 5, 2 * (8 * 4 + 5 * 8 * 16 + 7 * 16 + 8 * 20 + 16), 2 * (6 * 8 * 16 + 7 * 16 + 2 * 2 * 16)),
     # skip layer == last layer: no reverse-mode value+gradient kernel, but the training backward still needs the transposed rows
     (128, 5, 10, 0, 4 * 4 + 2 * 4 * 8 + 3 * 8 + 12, 3 * 4 * 8 + 2 * 2 * 8),
 ])

@@ -89,7 +89,9 @@ def test_render_without_importance_sampling_vs_reference_golden(case, netname):
 # measured on MI355X (round 4) + margin: 99.9th percentile of the element-wise relative error (floor 1e-6 of the tensor's max)
 # (measured: udf 1.1e-6 / 9.7e-7 / 2.3e-5; grad_x forward-mode kernel 6.3e-4 / 3.0e-4 / 2.3e-5, reverse sweep with MX-fp6 cross terms
 #  1.3e-2 / 5.8e-3 - components 1e-4 .. 1e-6 of the largest one carry the same ABSOLUTE error as the large ones; edge 2.3e-5)
-P999_BOUND = {"udf": 2e-4, "gradients_fwd": 2e-3, "gradients_rev": 4e-2, "edge": 2e-4}
+# round 5: "gradients_rev" tightened from 4e-2 to measurement (1.2e-2 / 6.8e-3 on the three boxes of rounds 4-5) + margin; what it consists of is
+# attributed in profiles/r05_elementwise_attribution.txt and tests/test_gpu_round5.py (fp32 floor 6.6e-4; unorm16 sigma' stash 5.7e-3; MX cross terms 1.2e-2)
+P999_BOUND = {"udf": 2e-4, "gradients_fwd": 2e-3, "gradients_rev": 2e-2, "edge": 2e-4}
 
 
 @pytest.mark.parametrize("name", ["d8w256L10", "d8w256L6", "d4w128L10"])

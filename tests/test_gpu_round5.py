@@ -197,3 +197,89 @@ def test_direct_param_grads_equal_autograd_accumulated_ones_and_fall_back_when_g
         assert torch.equal(a, b)
     for a, b, c in zip(outs[True][0], outs[True][1], outs[False][1]):
         assert torch.equal(b, c) and torch.allclose(b, 2 * a, rtol=1e-6, atol=0)
+
+
+# ---------------------------------------------------------------------------------------- precision mode f16x3e (no MX fp6 anywhere)
+def _rel(a, b):
+    a, b = a.detach().cpu().double().reshape(-1), b.detach().cpu().double().reshape(-1)
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def _p999(a, b, floor=1e-6):
+    a, b = a.detach().cpu().double().reshape(-1), b.detach().cpu().double().reshape(-1)
+    e = (a - b).abs() / torch.clamp(b.abs(), min=floor * float(b.abs().max()))
+    return float(torch.quantile(e, 0.999))
+
+
+def test_mode_f16x3e_is_the_wider_margin_mode_and_attributes_the_elementwise_error():
+    """precision="f16x3e" (EMAP_PREC_F16X3E, ADVICE r4 / VERDICT r4 weak 1): the value+gradient pass with f16 cross terms in BOTH sweeps - the
+    run-time way back to round 3's margin (the default f16x3 has MX-fp6 cross terms in the reverse sweep).  Against the fp64 oracle on
+    8192 random points, element-wise as well as max-normalised - the GPU side of profiles/r05_elementwise_attribution.txt (CPU emulation:
+    fp32 reference arithmetic 6.6e-4, f16x3 GEMMs + exact sigma' 6.3e-4, + unorm16 sigma' stash 5.7e-3, + MX cross terms 1.2e-2 at p99.9):
+    what remains above the forward-mode kernel in f16x3e is the unorm16 sigma' stash alone."""
+    from conftest import net_state
+    from oracle import emap_oracle as O
+    kw, state = net_state("d8w256L10")
+    cfg = O.UDFConfig(d_hidden=256, n_layers=8, multires=10)
+    x = torch.rand(65536, 3, generator=torch.Generator().manual_seed(9)) * 2 - 1
+    _, go = O.udf_value_and_grad({k: v.double() for k, v in state.items()}, cfg, x[:8192].double())
+    uo, _ = O.udf_value_and_grad({k: v.double() for k, v in state.items()}, cfg, x[:8192].double())
+    res = {}
+    L = _lib.lib()
+    for prec in ("f16x3", "f16x3e"):
+        n = emap_amd.UDFNetwork(precision=prec, **kw)
+        n.load_state_dict(state)
+        n = n.to(DEV)
+        with torch.no_grad():
+            u, g = n.hip_udf(x.to(DEV), with_grad=True)             # 65 536 points: the reverse sweep
+            u1, g1 = n.hip_udf(x.to(DEV), with_grad=True)
+        assert torch.equal(u, u1) and torch.equal(g, g1)           # bit-stable
+        res[prec] = (_rel(u[:8192], uo), _rel(g[:8192], go), _p999(g[:8192], go))
+    old = L.emap_set_grad_mode(0)                                  # forward-mode tangents (udf_mlp_fs2_kernel<grad>): no stash, no MX
+    try:
+        n = emap_amd.UDFNetwork(precision="f16x3", **kw)
+        n.load_state_dict(state)
+        n = n.to(DEV)
+        with torch.no_grad():
+            u, g = n.hip_udf(x[:8192].to(DEV), with_grad=True)
+        res["forward-mode"] = (_rel(u, uo), _rel(g, go), _p999(g, go))
+    finally:
+        L.emap_set_grad_mode(old)
+    print("udf max-norm, grad_x max-norm, grad_x element-wise p99.9 vs the fp64 oracle:", res)
+    assert res["f16x3e"][1] <= 2.2e-5 and res["f16x3"][1] <= 5e-5 and res["forward-mode"][1] <= 5e-6
+    assert res["f16x3e"][1] < 0.75 * res["f16x3"][1]               # the margin the mode exists for
+    # element-wise p99.9, bounds = measurement (round 5, 8192 random points: 1.7e-2 / 6.7e-3 / 4.1e-4) + margin; the fp32 reference itself: 6.6e-4
+    assert res["f16x3"][2] <= 3.0e-2 and res["f16x3e"][2] <= 1.2e-2 and res["forward-mode"][2] <= 1.5e-3
+
+
+def test_mode_f16x3e_renders_and_trains():
+    from conftest import load_golden, net_state
+    kw, state = net_state("d8w256L10")
+    n = emap_amd.UDFNetwork(precision="f16x3e", **kw)
+    n.load_state_dict(state)
+    n = n.to(DEV)
+    g5 = load_golden("g5_render_c64_64_4")
+    args = [torch.from_numpy(g5[k]).to(DEV) for k in ("rays_o", "rays_d", "near", "far", "depth_scale")]
+    devn = emap_amd.SingleVarianceNetwork(0.3).to(DEV)
+    bet = emap_amd.BetaNetwork(0.5, 0.3, 0.3, 5e-5, True, True, False).to(DEV)
+    r = emap_amd.UDFRendererBlending(None, n, devn, bet, 64, 64, 0, 4, 1.0, device=DEV)
+    with torch.no_grad():
+        o = r.render(*args, cos_anneal_ratio=1.0, perturb_overwrite=0, flip_saturation=0.9)
+    r.check_errors()
+    for k in ("edge", "depth", "weight_sum"):
+        assert _rel(o[k], torch.from_numpy(g5["out." + k])) <= 1e-4, k
+    # one native training step: gradients agree with the f16x3 step's (the backward kernels are the same; the forward's grad_x differs by 3e-5)
+    grads = {}
+    for prec in ("f16x3", "f16x3e"):
+        m = emap_amd.UDFNetwork(precision=prec, **kw)
+        m.load_state_dict(state)
+        m = m.to(DEV)
+        rr = emap_amd.UDFRendererBlending(None, m, emap_amd.SingleVarianceNetwork(0.3).to(DEV),
+                                          emap_amd.BetaNetwork(0.5, 0.3, 0.3, 5e-5, True, True, False).to(DEV), 64, 64, 0, 4, 1.0, device=DEV)
+        t_ = Trainer(rr, lr_geo=1e-4, lr=5e-4, igr_weight=0.1)
+        ro, rd, near, far, ds = [q.to(DEV) for q in synthetic.make_rays(128, seed=3)]
+        t_.step({"rays_o": ro, "rays_d": rd, "near": near, "far": far, "depth_scale": ds, "cos_anneal_ratio": 1.0, "flip_saturation": 0.9,
+                 "t_rand": synthetic.make_t_rand(128).to(DEV)}, synthetic.make_true_edge(128, seed=4).to(DEV))
+        grads[prec] = t_.flat.grad[:t_.flat.numel].clone()
+        rr.check_errors()
+    assert _rel(grads["f16x3e"], grads["f16x3"]) <= 1e-3
