@@ -39,7 +39,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 # the PMC passes of the dominant kernels recorded by scripts/profile_round.sh for this round's kernels (static: not measured in a bench run)
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r04_traffic.json")
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r05_traffic.json")
 sys.path.insert(0, ROOT)
 
 F_POINT = 918016          # FLOP per MLP point-forward, d8 w256 (SURVEY par. 7.0 / 8d)
@@ -192,6 +192,23 @@ def train_key(dev, precision, rays, S, steps=40, warmup=10):
            "ms_per_step": dt * 1e3, "ms_per_step_median": med, "value": value, "unit": "ray-samples/s",
            "whole_step_algorithmic_tflops": value * A_TRAIN / 1e12, "whole_step_frac": value * A_TRAIN / 1e12 / MFMA_PEAK_TFLOPS,
            "launch": "eager", "loss_after_run": trainer.last_stats.tolist(), "traffic": None}
+    # the same step replayed from ONE captured hipGraph (sampler, jitter draw, pack, forward, backward, Adam, loss): the launch mode
+    # `--mode train --graph on` times; `ms_per_step` above stays the eager figure of rounds 2-4
+    try:
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                step()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            step()
+        dt_g, med_g = _timed(graph.replay, steps, warmup)
+        out["graph_replay"] = {"ms_per_step": dt_g * 1e3, "ms_per_step_median": med_g, "value": rays * S / dt_g}
+    except Exception as e:   # pragma: no cover
+        out["graph_replay"] = {"error": repr(e)}
+        torch.cuda.synchronize()
     tpath = TRAFFIC_JSON
     if os.path.exists(tpath) and rays * S == 65536:
         try:
@@ -446,6 +463,7 @@ def cpu_baseline(state, kw, n_rays, mode):
     ncpu = os.cpu_count() or 1
     config = lambda t, b: _cpu_config(state, kw, n_rays, mode, t, b)
     res = [config(min(32, ncpu), 10.0), config(1, 6.0)]
+    skipped = []
     if ncpu > 32:
         # all host cores (BASELINE.md par. 3): eager torch on these ~1e5-element ops collapses when oversubscribed (measured on the
         # 256-thread EPYC 9575F host: 50 s for 32 rays, 5e2 ray-samples/s), so that configuration runs in a child process with a
@@ -456,9 +474,13 @@ def cpu_baseline(state, kw, n_rays, mode):
         try:
             out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=25)
             ln = [x for x in out.stdout.splitlines() if x.startswith("CFG")]
-            res.append(json.loads(ln[-1][3:]) if ln else {"threads": ncpu, "rays": 0, "runs": 0, "ms": None, "value": 0.0, "note": "failed"})
+            if ln:
+                res.append(json.loads(ln[-1][3:]))
+            else:
+                skipped.append({"threads": ncpu, "note": "the child process produced no sample"})
         except subprocess.TimeoutExpired:
-            res.append({"threads": ncpu, "rays": 32, "runs": 0, "ms": None, "value": 0.0, "note": "no 32-ray run finished within 25 s"})
+            # no sample = no entry: eager torch on 256 threads collapses on these ~1e5-element ops (round 3: 50 s for 32 rays)
+            skipped.append({"threads": ncpu, "note": "no 32-ray run finished within 25 s (oversubscribed eager torch); not part of `best of`"})
     torch.set_num_threads(min(32, ncpu))
     best = max(res, key=lambda c: c["value"])
     one = [c for c in res if c["threads"] == 1][0]
@@ -466,6 +488,7 @@ def cpu_baseline(state, kw, n_rays, mode):
     return {"value": best["value"], "unit": "ray-samples/s", "cores": best["threads"], "kind": "port", "cpu_model": cpu_model(),
             "host_cores": ncpu, "single_thread_value": one["value"],
             "by_threads": {str(c["threads"]): {k: c[k] for k in c if k != "threads"} for c in res},
+            "configurations_without_a_sample": skipped,
             "sample": f"{best['rays']} rays x 128 samples, {what}, median of {best['runs']} runs ({best['ms'] or 0:.0f} ms each) on "
                       f"{best['threads']} threads (best of {sorted(c['threads'] for c in res)} threads); oracle/emap_oracle.py on torch CPU fp32"}
 
