@@ -384,7 +384,7 @@ __device__ __forceinline__ void pack32_t_body(const PackArgs& a, unsigned block)
     //   @6 KiB     W_hi6 q4..q5 (8 B / lane)                   @6.5 KiB  W_lo6 q4..q5
     //   @7 KiB     8 B / lane: E8M0 scales of this lane's blocks of steps Sg .. Sg+3, byte 2 j + (hi6 | lo6) for step Sg + j
     // The cross terms W_hi x_lo + W_lo x_hi of the reverse sweep run as MX-scaled fp6 (e2m3) MFMAs of K = 64
-    // (v_mfma_scale_f32_32x32x64_f8f6f4, 4x the f16 rate; DESIGN.md par. 6c): lane (hh, i) of an fp6 block holds the 32 k-slots
+    // (v_mfma_scale_f32_32x32x64_f8f6f4, 4x the f16 rate; docs/DESIGN_LOG_r1-r4.md par. 6c): lane (hh, i) of an fp6 block holds the 32 k-slots
     // e = 16 pi + 8 u + e' <-> (S = 2Sg + pi, u, hh, e') of row i - the order in which a sweep lane holds its two row tiles' outputs -
     // as six registers of e2m3.  hi6 quantises the f16 hi parts, lo6 the lo parts (x 2^11 in f16, undone in the scale byte); both
     // through v_cvt_scalef32_pk32_fp6_f16, the instruction the sweep itself uses for its B operands (probed: natural element order,

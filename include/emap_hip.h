@@ -48,7 +48,7 @@ extern "C" {
 #define EMAP_PREC_F16X3 3       /* split fp16, three passes (~2^-22): the mode of the 1e-4 parity gate */
 #define EMAP_PREC_F16X3M 4      /* EMAP_PREC_F16X3 with the cross terms of the value+gradient pass's FORWARD sweep as MX fp6 too (its
                                    reverse sweep has them in every split-fp16 build): d_hidden = 256 only; the kernel ~10 % faster,
-                                   grad_x 6.2e-5 instead of 3.0e-5 of the 1e-4 gate (DESIGN.md par. 6c); every other kernel = F16X3 */
+                                   grad_x 6.2e-5 instead of 3.0e-5 of the 1e-4 gate (docs/DESIGN_LOG_r1-r4.md par. 6c); every other kernel = F16X3 */
 
 #define EMAP_PREC_F16X3E 5      /* EMAP_PREC_F16X3 with f16 cross terms in BOTH sweeps of the value+gradient pass (no MX fp6 anywhere): the round-3
                                    arithmetic - grad_x 1.5e-5 (max-normalised) / 7.7e-3 (element-wise p99.9) instead of 3.0e-5 / 1.2e-2, the kernel

@@ -1,4 +1,4 @@
-// Probe for the "one wave per SIMD, statically scheduled" candidate (DESIGN.md par. 7): a K-step of the reverse-sweep kernel
+// Probe for the "one wave per SIMD, statically scheduled" candidate (docs/DESIGN_LOG_r1-r4.md par. 7): a K-step of the reverse-sweep kernel
 // at a 128-point tile is 12 v_mfma_f32_32x32x16_f16 + 4 fragment loads (1 KiB each, L2-resident) + 16 ds_read_b128 + a share of
 // the epilogue VALU (NV per MFMA).  Everything but the MFMAs is placed between them.  How many cycles per K-step does ONE wave
 // per SIMD need, against 12 x 32 = 384?

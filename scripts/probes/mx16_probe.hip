@@ -1,5 +1,5 @@
 // mx16_probe.hip - v_mfma_scale_f32_16x16x128_f8f6f4 with e2m3 operands (the MX instruction a 16x16-tile kernel - the training sweep
-// udf_mlp_vjp.inc - would use; DESIGN.md par. 7):  (1) operand / result layout and per-lane E8M0 scales against a host computation,
+// udf_mlp_vjp.inc - would use; docs/DESIGN_LOG_r1-r4.md par. 7):  (1) operand / result layout and per-lane E8M0 scales against a host computation,
 // (2) issue rate next to v_mfma_f32_16x16x32_f16.
 // Hypothesis checked: A lane l = row l % 16, k-block l / 16 (32 consecutive k); B lane l = column l % 16, k-block l / 16; C as every 16x16
 // MFMA (lane l: column l % 16, rows 4 (l / 16) + r); scale = byte 0 of the scale register of the lane that holds the block.

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""CPU emulation of the MX (block-scaled fp8 / fp6) cross terms of udf_mlp_rev32_kernel<256, f16x3> - the numbers behind DESIGN.md par. 6c.
+"""CPU emulation of the MX (block-scaled fp8 / fp6) cross terms of udf_mlp_rev32_kernel<256, f16x3> - the numbers behind docs/DESIGN_LOG_r1-r4.md par. 6c.
 
 Extends precision_emulation.py (exact products of f16 operands, fp32 sums) with GEMM variants whose cross terms W_hi x_lo + W_lo x_hi use
 MX operands: 32-value blocks in the kernel's own block shape (the 32 values one lane holds of a K64-step: features 32 (2 Sigma + t) + R(r, hh)),

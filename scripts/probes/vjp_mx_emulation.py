@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """CPU emulation: what would MX-fp6 cross terms in the TRAINING sweep (udf_mlp_vjp_kernel: forward with a tangent column, backward with two
-adjoint columns) do to dL/dW?  The candidate for the next round (DESIGN.md par. 7): the sweep is MFMA-bound below the power cap, its
+adjoint columns) do to dL/dW?  The candidate for the next round (docs/DESIGN_LOG_r1-r4.md par. 7): the sweep is MFMA-bound below the power cap, its
 GEMMs are split-fp16 with f16 cross terms (3 passes), and its consumer - the weight-gradient GEMM on f16 hi parts - is good to 4e-4
 of each tensor's maximum, an order of magnitude looser than what the value+gradient pass had to meet.
 
