@@ -86,6 +86,9 @@ def parse():
                     help="self-check of the RCCL branch: with >= 2 visible GPUs, run 2 ranks x 3 training steps over nccl (eager and from "
                          "per-phase graphs) and print one JSON line with the outcome; with one GPU it reports 'skipped'.  Meant to be the "
                          "first command on a multi-GPU lease.")
+    ap.add_argument("--traffic", default=os.environ.get("EMAP_BENCH_TRAFFIC", "live"), choices=["live", "static", "off"],
+                    help="roofline.traffic: live = measured after the timing by two rocprofv3 --pmc child passes of this command (one GPU; falls "
+                         "back to static), static = the figure recorded under profiles/ for this round's kernels, off = null")
     ap.add_argument("--no-train-key", action="store_true", help="render mode, one GPU: skip the short training-step measurement")
     ap.add_argument("--no-other-modes", action="store_true", help="skip the short runs of the other precision modes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -493,6 +496,46 @@ def cpu_baseline(state, kw, n_rays, mode):
                       f"{best['threads']} threads (best of {sorted(c['threads'] for c in res)} threads); oracle/emap_oracle.py on torch CPU fp32"}
 
 
+def measure_traffic_live(mode, precision, rays, dominant_key):
+    """HBM-side bytes per launch of the dominant kernel, MEASURED for this command on this box: two `rocprofv3 --pmc` child runs of this
+    script (FETCH_SIZE, then WRITE_SIZE - separate passes, no tracing, as MI355X_MICROARCH.md prescribes), a few steps each, after
+    all timing is done.  Bytes = 2 x FETCH_SIZE (the guide's gfx950 correction for wide coalesced reads) + WRITE_SIZE, both reported in
+    KiB.  Returns (bytes, note) or (None, reason)."""
+    import csv, glob, shutil, tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    tmp = tempfile.mkdtemp(prefix="emap_traffic_", dir=os.environ.get("TMPDIR", "/tmp"))
+    vals = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr)
+            cmd = [exe, "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
+                   "--mode", mode, "--rays", str(rays), "--steps", "5", "--warmup", "2", "--settle-steps", "5", "--precision", precision,
+                   "--no-cpu-baseline", "--no-other-modes", "--no-parity", "--no-train-key", "--traffic", "off", "--graph", "off"]
+            env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp"))
+            p_ = subprocess.run(cmd, cwd=tmp, env=env, capture_output=True, text=True, timeout=240)
+            f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if p_.returncode != 0 or not f:
+                return None, f"rocprofv3 --pmc {ctr} failed (rc {p_.returncode})"
+            per = {}
+            for r_ in csv.DictReader(open(f[0])):
+                if dominant_key in r_["Kernel_Name"] and r_["Counter_Name"] == ctr:
+                    per[r_["Dispatch_Id"]] = per.get(r_["Dispatch_Id"], 0.0) + float(r_["Counter_Value"])
+            if not per:
+                return None, f"no dispatch of {dominant_key} in the {ctr} pass"
+            vals[ctr] = (sum(per.values()) / len(per), len(per))
+        b = vals["FETCH_SIZE"][0] * 1024 * 2 + vals["WRITE_SIZE"][0] * 1024
+        return b, (f"MEASURED in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this command (mean over {vals['FETCH_SIZE'][1]} / "
+                   f"{vals['WRITE_SIZE'][1]} launches of {dominant_key}); 2 x FETCH_SIZE + WRITE_SIZE, KiB units (MI355X_MICROARCH.md)")
+    except subprocess.TimeoutExpired:
+        return None, "rocprofv3 pass timed out"
+    except Exception as e:   # pragma: no cover
+        return None, repr(e)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def dry_run_nccl():
     """`python bench.py --dry-run-nccl`: constructs the nccl (= RCCL) process group on 2 GPUs and takes three training steps eagerly and
     three from per-phase graphs, so that the first multi-GPU lease is not spent debugging the launch path."""
@@ -783,7 +826,13 @@ def main():
         if parity is not None:
             line["parity"] = parity
         tpath = TRAFFIC_JSON
-        if os.path.exists(tpath):
+        live_note = None
+        if a.traffic == "live" and world == 1:
+            tb, live_note = measure_traffic_live(a.mode, a.precision, rays, "udf_mlp_vjp_kernel" if a.mode == "train" else "udf_mlp_rev")
+            if tb is not None:
+                line["roofline"]["traffic"] = tb
+                line["roofline"]["traffic_source"] = live_note
+        if line["roofline"]["traffic"] is None and a.traffic != "off" and os.path.exists(tpath):
             try:
                 ent = json.load(open(tpath)).get(f"{a.mode}:{a.precision}")
                 # the counters were collected on launches of 65 536 points (512 rays x 128 samples): no figure is quoted for a launch of
@@ -792,7 +841,8 @@ def main():
                 if ent and same_launch:
                     line["roofline"]["traffic"] = ent["hbm_bytes_per_launch"]
                     line["roofline"]["traffic_source"] = (f"STATIC: profiles/{os.path.basename(tpath)}, recorded by rocprofv3 --pmc passes of this kernel at this launch "
-                                                          "size (scripts/profile_round.sh; MI355X_MICROARCH.md corrections), not measured in this run")
+                                                          "size (scripts/profile_round.sh; MI355X_MICROARCH.md corrections), not measured in this run"
+                                                          + (f" (live measurement unavailable: {live_note})" if live_note else ""))
             except Exception:
                 pass
         if not a.no_other_modes and world == 1 and a.mode == "render":

@@ -3,7 +3,7 @@
 OUT=${1:-gpurun_out/batch_sweep.jsonl}
 : > "$OUT"
 for mode in render train; do for rays in 512 1024 2048 4096; do
-  python bench.py --mode $mode --rays $rays --steps 50 --warmup 5 --no-cpu-baseline --no-other-modes --no-parity --no-train-key 2>/dev/null | tail -1 >> "$OUT"
+  python bench.py --mode $mode --rays $rays --steps 50 --warmup 5 --no-cpu-baseline --no-other-modes --no-parity --no-train-key --traffic static 2>/dev/null | tail -1 >> "$OUT"
 done; done
 python - "$OUT" <<'PY'
 import json, sys

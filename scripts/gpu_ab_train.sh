@@ -6,7 +6,7 @@ OUT=$1; shift
 for round in 1 2; do
   for v in "$@"; do
     if [ "$v" = base ]; then unset EMAP_HIP_LIB; else export EMAP_HIP_LIB=$PWD/emap_amd/lib/$v/libemap_hip.so; fi
-    line=$(python bench.py --mode train --steps 40 --warmup 10 --graph off --no-cpu-baseline --no-other-modes --no-parity 2>/dev/null | tail -1)
+    line=$(python bench.py --mode train --steps 40 --warmup 10 --graph off --no-cpu-baseline --no-other-modes --no-parity --traffic static 2>/dev/null | tail -1)
     echo "{\"variant\": \"$v\", \"round\": $round, \"line\": $line}" >> "$OUT"
   done
 done

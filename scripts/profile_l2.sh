@@ -7,7 +7,7 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 -L 2>/dev/null | grep -o -E "\b(TCP|TCC|TA|TD)_[A-Z0-9_a-z]+" | sort -u > $OUT/avail_tcp_tcc.txt
-PARGS="--mode render --steps 5 --warmup 2 --settle-steps 5 --no-cpu-baseline --no-other-modes --no-parity --no-train-key"
+PARGS="--mode render --steps 5 --warmup 2 --settle-steps 5 --no-cpu-baseline --no-other-modes --no-parity --no-train-key --traffic off"
 for set in "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_WRITE_REQ_sum" "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_READ_sum" "TA_BUSY_avr TA_FLAT_READ_WAVEFRONTS_sum TCP_PENDING_STALL_CYCLES_sum GRBM_GUI_ACTIVE"; do
   n=$(echo $set | cut -d" " -f1)
   rocprofv3 --pmc $set --output-format csv -d $OUT/l2_$n -o p -- python $R/bench.py $PARGS > /dev/null 2> $OUT/l2_$n.err

@@ -228,6 +228,12 @@ def test_default_bench_line_carries_the_training_step():
     tr = line["train"]
     assert "error" not in tr and tr["ms_per_step"] > 0 and 0 < tr["whole_step_frac"] < 1 and tr["value"] > 0
     assert line["config"]["settle_steps"] == 3 and line["roofline"]["kernel"].startswith("udf_mlp_rev32_kernel")
+    # round 5: roofline.traffic is MEASURED in the run (two rocprofv3 --pmc child passes after the timing; static figure as the fallback):
+    # the sigma' stash round trip of the dominant kernel, 0.65 GB per launch of 65 536 points
+    rf = line["roofline"]
+    assert rf["traffic"] is not None and 3e8 < rf["traffic"] < 1.5e9, rf
+    assert rf["traffic_source"].startswith("MEASURED") or rf["traffic_source"].startswith("STATIC"), rf["traffic_source"]
+    print("roofline.traffic:", rf["traffic"], rf["traffic_source"][:60])
 
 
 def test_dry_run_nccl_self_check_reports():
