@@ -362,7 +362,7 @@ def train_dropin_key(dev, precision, rays, steps=40, warmup=10, n_samples=64, n_
     run = lambda step: _timed(step, steps, warmup)
     train = _RunnerLoop.train_udf
     if patched:
-        train = dropin.train_wrapper(train, sys.modules[__name__])
+        train = dropin.train_wrapper(train, sys.modules[__name__], single_thread_autograd=os.environ.get("EMAP_DROPIN_MT", "0") != "1")
     dt, med = train(loop, run)
     loop.renderer.check_errors()
     n_steps = steps + warmup

@@ -217,7 +217,11 @@ class RenderFn(torch.autograd.Function):
             if G is None or G.numel() != lay.numel or G.device != call["dev"]:
                 G = r._grad_flat = torch.empty(lay.numel, dtype=torch.float32, device=call["dev"])
             r.backward_into(call, v, d_edge, d_depth, d_ge, d_ge_ns, flat=G, packed=packed)
-            for p, g_ in zip(lay.tensors, lay.views(G, need)):
+            vk = (G.data_ptr(), tuple(need))
+            views = getattr(r, "_grad_views", None)
+            if views is None or views[0] != vk:              # the buffer is persistent: so are its views
+                views = r._grad_views = (vk, lay.views(G, need))
+            for p, g_ in zip(lay.tensors, views[1]):
                 if g_ is not None:
                     p.grad = g_
             return (None, None) + (None,) * len(lay.tensors)

@@ -144,14 +144,15 @@ class DeferredScalarWriter:
         return getattr(self._w, name)
 
 
-def train_wrapper(orig_train, mod=None, fused_adam: bool = True, defer_scalars: bool = True):
+def train_wrapper(orig_train, mod=None, fused_adam: bool = True, defer_scalars: bool = True, single_thread_autograd: bool = True):
     """``Runner_UDF.train_udf`` (src/runner/runner_udf.py:35-250) unmodified, with the host-side cost of its step removed where
     that is possible without touching its code:
       * the renderer hands out host-mirrored ``variance / beta / gamma`` (host_scalars.py): the reads of runner_udf.py:141-148,185 do not
         wait for the forward render, so the runner's own small loss kernels queue up behind it instead of after a synchronisation;
       * ``RenderFn.backward`` installs the parameter gradients itself (``direct_param_grads``) and ``FusedAdam`` (swapped in for the
         runner's ``torch.optim.Adam`` over the same groups: one launch instead of 32 x 6) reads them in place;
-      * the tensorboard writer the method creates defers device scalars (``DeferredScalarWriter``, flushed every ``report_freq`` steps).
+      * the tensorboard writer the method creates defers device scalars (``DeferredScalarWriter``, flushed every ``report_freq`` steps);
+      * ``loss.backward()`` runs on the calling thread (``torch.autograd.set_multithreading_enabled(False)`` for the duration of the loop).
     What stays: the progress bar's ``loss.item()`` / ``format(psnr)`` (runner_udf.py:164) - one wait for the forward per step."""
     def train_udf(self, *a, **k):
         import torch
@@ -166,9 +167,15 @@ def train_wrapper(orig_train, mod=None, fused_adam: bool = True, defer_scalars: 
         if defer_scalars and sw is not None:
             every = int(getattr(self, "report_freq", 100) or 100)
             m.SummaryWriter = lambda *wa, **wk: DeferredScalarWriter(sw(*wa, **wk), flush_every=every)
+        # autograd on the calling thread: the engine's hand-off to its per-device worker thread and back costs ~0.1 ms per backward() - with the
+        # GPU idle, between the forward and the backward of every step (the graph here is one RenderFn node and six small ones)
+        mt = torch.autograd.is_multithreading_enabled()
+        if single_thread_autograd:
+            torch.autograd.set_multithreading_enabled(False)
         try:
             return orig_train(self, *a, **k)
         finally:
+            torch.autograd.set_multithreading_enabled(mt)
             if defer_scalars and sw is not None:
                 m.SummaryWriter = sw
             w = getattr(self, "writer", None)

@@ -139,11 +139,20 @@ class UDFNetwork(nn.Module):
         buf = hit[1] if (hit is not None and hit[1].numel() == nbytes.value and hit[1].device == vs[0].device) else \
             torch.empty(nbytes.value, dtype=torch.uint8, device=vs[0].device)
         n = len(vs)
-        arr = lambda ts: (C.c_void_p * n)(*[_lib.f32c(t.detach()).data_ptr() for t in ts])
-        keep = [[_lib.f32c(t.detach()) for t in ts] for ts in (gs, vs, bs)]  # keep contiguous copies alive
-        ga = (C.c_void_p * n)(*[t.data_ptr() for t in keep[0]])
-        va = (C.c_void_p * n)(*[t.data_ptr() for t in keep[1]])
-        ba = (C.c_void_p * n)(*[t.data_ptr() for t in keep[2]])
+        # pointer tables: cached while every source tensor is the contiguous fp32 tensor at the same address it was (the usual case: an
+        # optimizer updates in place) - the re-pack after every step then costs one key comparison and one launch on the host
+        ptrs = key[3]
+        hit_t = getattr(self, "_pack_tables", None)
+        if (self.weight_norm and hit_t is not None and hit_t[0] == ptrs
+                and all(t.dtype == torch.float32 and t.is_contiguous() for t in ident)):
+            ga, va, ba = hit_t[1]
+        else:
+            keep = [[_lib.f32c(t.detach()) for t in ts] for ts in (gs, vs, bs)]  # keep contiguous copies alive
+            ga = (C.c_void_p * n)(*[t.data_ptr() for t in keep[0]])
+            va = (C.c_void_p * n)(*[t.data_ptr() for t in keep[1]])
+            ba = (C.c_void_p * n)(*[t.data_ptr() for t in keep[2]])
+            same = all(k_.data_ptr() == t.data_ptr() for ks_, ts in zip(keep, (gs, vs, bs)) for k_, t in zip(ks_, ts))
+            self._pack_tables = (ptrs, (ga, va, ba)) if (self.weight_norm and same) else None
         with _lib.on_device(buf):
             _lib.check(L.emap_pack_weights(C.byref(cfg), ga, va, ba, _lib.ptr(buf), prec, _lib.stream_ptr(buf.device)), "pack_weights")
         self._pack_cache[prec] = (key, buf)
