@@ -71,11 +71,24 @@ struct NetLayout {
     // the same two fragment sets in the K order of the 32x32x16 kernels (udf_mlp_rev32.inc): same fragment counts and the
     // same per-layer offsets (frag_off, t_off, tpe_off), a fragment = 32 rows x 16 k, index [row tile][K32-step][u][part]
     int32_t r32_frag_off_bytes, r32_t_frag_off_bytes;
+    // "swm": the MX-fp6 operands of the TRAINING sweep's cross terms (udf_mlp_vjp.inc, round 5), split-fp16 at d_hidden = 256 (not in
+    // EMAP_PREC_F16X3E): one unit of SWM_UNIT_BYTES per (GEMM, tile pair p, K128-step S) - W_hi and W_lo of the pair's two 16-row tiles
+    // as e2m3 in the A layout of v_mfma_scale_f32_16x16x128_f8f6f4 (lane l: row l % 16, k-block l / 16 = K-step 4 S + l / 16) + their E8M0 bytes.
+    //   swm_unit[l]    first unit of forward layer l's hidden-K GEMM (l >= 1; units [pair][S]), -1 if none
+    //   swm_t_unit[l]  first unit of reverse step b = l (rows = input features of layer l, K = its output features), -1 if none
+    int32_t sweep_mx, swm_off_bytes, swm_units;
+    int32_t swm_unit[EMAP_MAX_LIN], swm_t_unit[EMAP_MAX_LIN];
     LayerDesc layer[EMAP_MAX_LIN];
 };
+// unit layout: fp6 registers q0..q3 of block (t, part6) at (2 t + part6) KiB + 16 lane; q4..q5 at 4 KiB + (2 t + part6) 512 + 8 lane;
+// scale bytes at 6 KiB + 4 lane + (2 t + part6)      (part6: 0 = W_hi6, 1 = W_lo6, whose byte already undoes the x 2^11 of the lo parts)
+constexpr int SWM_UNIT_BYTES = 6656;
 
 // The transposed 32x32 section in the MIXED layout of the MX-fp6 reverse sweep (udf_mlp.hip:pack32_t_body, udf_mlp_rev32.inc):
 // split-fp16 at d_hidden = 256 (a sweep wave owns two row tiles = one 32-value MX block per lane)
+#ifndef EMAP_SWEEP_MX
+#define EMAP_SWEEP_MX 1     // 1: the training sweep's cross terms as MX-fp6 MFMAs (udf_mlp_vjp.inc, round 5); 0: three f16 passes as in rounds 1-4 (A/B builds: all units)
+#endif
 #ifndef EMAP_REV_MX6
 #define EMAP_REV_MX6 1      // 0: f16 cross terms in the backward GEMMs too (A/B builds: compile udf_mlp AND udf_mlp_f16x3 with the flag)
 #endif
@@ -98,7 +111,8 @@ __host__ __device__ inline uint32_t mx6_scale_bits(float m) {
 // returns 0 or EMAP_E_INVALID (error text set)
 int build_layout(const EmapNetConfig* cfg, int prec, NetLayout* L);
 inline size_t layout_bytes(const NetLayout& L) {
-    return (size_t)L.r32_t_frag_off_bytes + (size_t)L.t_total_frags * FRAG_BYTES;
+    const size_t base = (size_t)L.r32_t_frag_off_bytes + (size_t)L.t_total_frags * FRAG_BYTES;
+    return L.sweep_mx ? (size_t)L.swm_off_bytes + (size_t)L.swm_units * SWM_UNIT_BYTES : base;
 }
 
 // launchers implemented in the .hip files

@@ -397,6 +397,58 @@ __device__ __forceinline__ void pack32_t_body(const PackArgs& a, unsigned block)
                       [&](int S, int u, int e) -> float { return weight(col, S, u, e); });
 }
 
+// MX operands of the training sweep (emap_common.h "swm"): one thread per (unit, row tile t, lane); lane (kb, i) holds row 16 t + i of the
+// pair and the 32 k-values of K-step 4 S + kb in the element order idx = 8 g' + e  <->  feature 16 (2 s + (e >> 2)) + 4 g' + (e & 3): exactly what
+// the four lanes (g', i) of the f16 fragment (s, t) hold, and on the B side what the four lanes (g', column) of an output fragment hold.
+__device__ __forceinline__ void pack_swm_body(const PackArgs& a, unsigned block) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    const long long gid = (long long)block * 256 + threadIdx.x;
+    const int unit = (int)(gid >> 7), t = (int)((gid >> 6) & 1), lane = (int)(gid & 63);
+    if (unit >= a.L.swm_units) return;
+    const int H = a.L.H, n128 = H / 128;
+    int l = -1; bool tr = false;
+    for (int q = 1; q < a.L.n_lin; ++q) {
+        if (a.L.swm_unit[q] >= 0 && unit >= a.L.swm_unit[q] && unit < a.L.swm_unit[q] + a.L.layer[q].n_pairs * n128) { l = q; tr = false; }
+        if (a.L.swm_t_unit[q] >= 0 && unit >= a.L.swm_t_unit[q] && unit < a.L.swm_t_unit[q] + ((a.L.layer[q].in_prev + 31) / 32) * n128) { l = q; tr = true; }
+    }
+    if (l < 0) return;
+    const LayerDesc Ld = a.L.layer[l];
+    const int u = unit - (tr ? a.L.swm_t_unit[l] : a.L.swm_unit[l]);
+    const int p = u / n128, S = u % n128;
+    const int i = lane & 15, kb = lane >> 4, s = 4 * S + kb;
+    const float* rs = reinterpret_cast<const float*>(a.packed + a.L.rowscale_off_bytes);
+    const float mult = (l == a.L.skip_l) ? 0.70710678118654752440f : 1.0f;
+    const int n_in = a.in_dim[l];
+    const int row = 32 * p + 16 * t + i;          // forward: output feature; transposed: input feature (a column of W_l)
+    f16x32 vh, vl;
+    float mh = 0.f, ml = 0.f;
+#pragma unroll
+    for (int idx = 0; idx < 32; ++idx) {
+        const int gq = idx >> 3, e = idx & 7;
+        const int f = 16 * (2 * s + (e >> 2)) + 4 * gq + (e & 3);
+        float w = 0.f;
+        if (!tr) { if (row < Ld.out_dim && f < Ld.in_prev) w = rs[l * H + row] * a.v[l][(size_t)row * n_in + f] * mult; }
+        else { if (f < Ld.out_dim && row < Ld.in_prev) w = rs[l * H + f] * a.v[l][(size_t)f * n_in + row] * mult; }
+        const _Float16 h16 = (_Float16)w;
+        const _Float16 l16 = (_Float16)((w - (float)h16) * 2048.0f);
+        vh[idx] = h16; vl[idx] = l16;
+        mh = fmaxf(mh, fabsf((float)h16));
+        ml = fmaxf(ml, fabsf((float)l16));
+    }
+    const uint32_t sbh = mx6_scale_bits(mh), sbl = mx6_scale_bits(ml);
+    const u32x6 qh = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(vh, __builtin_bit_cast(float, sbh));
+    const u32x6 ql = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(vl, __builtin_bit_cast(float, sbl));
+    char* ub = a.packed + a.L.swm_off_bytes + (size_t)unit * SWM_UNIT_BYTES;
+    *reinterpret_cast<u32x4*>(ub + (2 * t + 0) * 1024 + lane * 16) = u32x4{qh[0], qh[1], qh[2], qh[3]};
+    *reinterpret_cast<u32x4*>(ub + (2 * t + 1) * 1024 + lane * 16) = u32x4{ql[0], ql[1], ql[2], ql[3]};
+    *reinterpret_cast<u32x2*>(ub + 4096 + (2 * t + 0) * 512 + lane * 8) = u32x2{qh[4], qh[5]};
+    *reinterpret_cast<u32x2*>(ub + 4096 + (2 * t + 1) * 512 + lane * 8) = u32x2{ql[4], ql[5]};
+    uint8_t* sc = reinterpret_cast<uint8_t*>(ub + 6144 + lane * 4);
+    sc[2 * t + 0] = (uint8_t)(sbh >> 23);
+    sc[2 * t + 1] = (uint8_t)((sbl >> 23) - 11u);
+}
+
 // fp32 copy of the last layer's real row (times its weight-norm scale): the seed of the reverse sweep
 __device__ __forceinline__ void pack_wlast_body(const PackArgs& a, unsigned block) {
     const int f = block * 256 + threadIdx.x;
@@ -464,6 +516,17 @@ int build_layout(const EmapNetConfig* cfg, int prec, NetLayout* L) {
     L->t_total_frags = tf;   // always packed: the training backward (udf_mlp_vjp.inc) needs it for every topology
     L->r32_frag_off_bytes = L->t_frag_off_bytes + tf * FRAG_BYTES;
     L->r32_t_frag_off_bytes = L->r32_frag_off_bytes + frag * FRAG_BYTES;
+    // MX operands of the training sweep (emap_common.h): hidden-K GEMMs of the forward layers 1 .. n_lin-1 (the last layer's one
+    // real row included: its x_lo fragments no longer exist in the sweep's exchange buffer) and of the reverse steps n_lin-2 .. 1
+    L->sweep_mx = (EMAP_SWEEP_MX && L->is_f16 && L->nparts == 2 && H == 256 && prec != EMAP_PREC_F16X3E && L->has_rev) ? 1 : 0;
+    L->swm_units = 0;
+    L->swm_off_bytes = (int32_t)(((size_t)L->r32_t_frag_off_bytes + (size_t)tf * FRAG_BYTES + 255) & ~(size_t)255);
+    for (int l = 0; l < cfg->n_lin; ++l) { L->swm_unit[l] = -1; L->swm_t_unit[l] = -1; }
+    if (L->sweep_mx) {
+        const int n128 = H / 128;
+        for (int l = 1; l < cfg->n_lin; ++l) { L->swm_unit[l] = L->swm_units; L->swm_units += L->layer[l].n_pairs * n128; }
+        for (int l = 1; l < cfg->n_lin - 1; ++l) { L->swm_t_unit[l] = L->swm_units; L->swm_units += ((L->layer[l].in_prev + 31) / 32) * n128; }
+    }
     return EMAP_OK;
 }
 
@@ -484,13 +547,14 @@ void build_vjp_layout(const NetLayout& L, VjpLayout* V) {
     V->s_slab_kb = (L.n_lin - 1) * (L.H / 32) * 4;   // per workgroup: [hidden layer][tile pair][4 x 64 lanes x 16 B] lane-linear (a', sigma')
 }
 
-__global__ __launch_bounds__(256) void pack_all_kernel(const PackArgs a, unsigned nb0, unsigned nb1) {
+__global__ __launch_bounds__(256) void pack_all_kernel(const PackArgs a, unsigned nb0, unsigned nb1, unsigned nb2) {
     const unsigned b = blockIdx.x;
     if (b < nb0) pack_body(a, b);
     else if (b < nb0 + nb1) pack_t_body(a, b - nb0);
     else if (b < 2 * nb0 + nb1) pack32_body(a, b - nb0 - nb1);
     else if (b < 2 * (nb0 + nb1)) pack32_t_body(a, b - 2 * nb0 - nb1);
-    else pack_wlast_body(a, b - 2 * (nb0 + nb1));
+    else if (b < 2 * (nb0 + nb1) + nb2) pack_wlast_body(a, b - 2 * (nb0 + nb1));
+    else pack_swm_body(a, b - 2 * (nb0 + nb1) - nb2);
 }
 
 int launch_pack(const NetLayout& L, const float* const* g, const float* const* v, const float* const* b,
@@ -509,7 +573,8 @@ int launch_pack(const NetLayout& L, const float* const* g, const float* const* v
     // training step re-packs after every optimizer update, and each launch of these small kernels is ~5 us of latency
     const long long tthreads = (long long)L.t_total_frags * 64;
     const unsigned nb0 = (unsigned)((threads + 255) / 256), nb1 = (unsigned)((tthreads + 255) / 256), nb2 = (unsigned)((L.H + 255) / 256);
-    hipLaunchKernelGGL(pack_all_kernel, dim3(2 * (nb0 + nb1) + nb2), dim3(256), 0, st, a, nb0, nb1);
+    const unsigned nb3 = L.sweep_mx ? (unsigned)(((long long)L.swm_units * 128 + 255) / 256) : 0u;
+    hipLaunchKernelGGL(pack_all_kernel, dim3(2 * (nb0 + nb1) + nb2 + nb3), dim3(256), 0, st, a, nb0, nb1, nb2);
     return check_launch("pack_weights");
 }
 

@@ -29,6 +29,7 @@ RE_RANGE = re.compile(r"\bv\[(\d+):(\d+)\]")
 RE_SINGLE = re.compile(r"\bv(\d+)\b")
 RE_VMCNT = re.compile(r"s_waitcnt\b.*vmcnt\((\d+)\)")
 RE_LOAD = re.compile(r"^\s*global_load_dwordx[234]\s+v\[(\d+):(\d+)\]")
+RE_LOAD1 = re.compile(r"^\s*global_load_dword\s+v(\d+)\b")      # one register (round 5: the E8M0 scale words of the MX sweep)
 RE_NOP = re.compile(r"^\s*s_nop\s+(\d+)")
 WAR_WINDOW = 2        # MFMAs this many instructions (or fewer) before an asm load are checked
 WAR_WAIT_STATES = 5   # required between such an MFMA and the load that overwrites one of its source registers
@@ -87,8 +88,10 @@ def lint(path):
                 if mn:
                     nops += int(mn.group(1)) + 1
                 m = RE_LOAD.match(s)
-                if m:
-                    dst = set(range(int(m.group(1)), int(m.group(2)) + 1))
+                m1 = RE_LOAD1.match(s) if not m else None
+                if m or m1:
+                    dst = set(range(int(m.group(1)), int(m.group(2)) + 1)) if m else {int(m1.group(1))}
+                    m = m or m1
                     between = nops
                     for is_mfma, src, ws in reversed(recent):
                         if is_mfma and (src & dst) and between < WAR_WAIT_STATES:
