@@ -31,9 +31,12 @@ t = np.frombuffer(buf, dtype=np.int64).reshape(32, 8, 64)
 def seg(a, b):
     d = (t[:, :, b] - t[:, :, a]).reshape(-1)
     return {"median": int(np.median(d)), "min": int(d.min()), "max": int(d.max())}
-names = [("fwd K-loop", 0, 1), ("fwd epilogue", 1, 2), ("fwd stash transposition + stores issued", 2, 3), ("fwd wait barrier A", 3, 4), ("fwd exchange writes", 4, 5),
-         ("fwd wait barrier B", 5, 6), ("fwd layer total", 0, 6),
-         ("bwd K-loop", 8, 9), ("bwd wait slab", 9, 10), ("bwd epilogue", 10, 11), ("bwd stash", 11, 7), ("bwd wait barrier A", 7, 12), ("bwd exchange writes", 12, 13),
-         ("bwd wait barrier B", 13, 14), ("bwd step total", 8, 14),
+# round 5 stamps: forward layer 2: 0 start, 1 K-loop done, 2 head request + epilogue done, 3 stash transposition + stores issued (publish entered), 4 exchange fragments
+# written, 5 MX block conversion + entries written (SMX builds; else = 4), 6 barrier passed; reverse step b = 3: 8 start, 9 K-loop done, 10 slab wait + head request + epilogue
+# done, 11 stash issued, 12 fragments written, 13 conversion done, 14 barrier; 16 tile start, 17 forward sweep done, 18 last layer + seeds, 19 reverse sweep done
+names = [("fwd K-loop", 0, 1), ("fwd head request + epilogue", 1, 2), ("fwd stash transposition + stores issued", 2, 3), ("fwd exchange fragment writes", 3, 4),
+         ("fwd MX block conversion + entry writes", 4, 5), ("fwd wait barrier", 5, 6), ("fwd layer total", 0, 6),
+         ("bwd K-loop", 8, 9), ("bwd slab wait + head request + epilogue", 9, 10), ("bwd stash", 10, 11), ("bwd exchange fragment writes", 11, 12),
+         ("bwd MX block conversion + entry writes", 12, 13), ("bwd wait barrier", 13, 14), ("bwd step total", 8, 14),
          ("PE + forward sweep", 16, 17), ("last layer + seeds", 17, 18), ("reverse sweep", 18, 19), ("tile total", 16, 19)]
 print(json.dumps({k: seg(a, b) for k, a, b in names}, indent=1))
