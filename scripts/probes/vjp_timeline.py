@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""s_memtime stamps of a -DEMAP_TIMELINE build of udf_mlp_vjp_kernel (git apply scripts/probes/vjp_timeline.patch; scripts/build_variant.sh vtl -DEMAP_TIMELINE):
+"""s_memtime stamps of a -DEMAP_TIMELINE build of udf_mlp_vjp_kernel (python scripts/probes/vjp_timeline_instrument.py; scripts/build_variant.sh vtl -DEMAP_TIMELINE; git checkout emap_amd/csrc):
 second tile of workgroups 0..31, every wave.  Forward layer 2: 0 start, 1 K-loop done, 2 epilogue done, 3 stash + slab stores issued, 4 barrier A,
 5 exchange written, 6 barrier B; backward step b = 3: 8 start, 9 K-loop done, 10 slab landed, 11 epilogue done, 7 stash issued, 12 / 13 / 14 = barrier A /
 exchange / barrier B; 16 tile start, 17 forward sweep done, 18 last layer + seeds done, 19 reverse sweep done."""
