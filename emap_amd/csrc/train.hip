@@ -49,7 +49,10 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, flo
                                                    float* tail_step) {
     const float t = *step + 1.0f;
     const float b2 = (float)b2d, omb1 = (float)(1.0 - b1d), omb2 = (float)(1.0 - b2d);
-    const float bc1 = (float)(1.0 - pow(b1d, (double)t)), bc2s = (float)sqrt(1.0 - pow(b2d, (double)t));
+    __shared__ float s_bc[2];      // the two double-precision powers once per workgroup, not once per thread (9 -> 12 us otherwise)
+    if (threadIdx.x == 0) { s_bc[0] = (float)(1.0 - pow(b1d, (double)t)); s_bc[1] = (float)sqrt(1.0 - pow(b2d, (double)t)); }
+    __syncthreads();
+    const float bc1 = s_bc[0], bc2s = s_bc[1];
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         float c1 = bc1, c2s = bc2s;
         if (i >= n_geo && tail_mask) {
