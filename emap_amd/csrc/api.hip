@@ -465,7 +465,7 @@ static size_t render_bwd_extra(const EmapRenderParams& p, size_t* off_du, size_t
     size_t off = 0;
     *off_du = off; off += align256(N * S * 4);
     *off_dg = off; off += align256(N * S * 12);
-    *off_part = off; off += align256(N * 16);
+    *off_part = off; off += align256(N * 16 + N * 8);      // composite_bwd's (N,4) partial sums + (N,2) per-ray maxima
     return off;
 }
 

@@ -410,9 +410,38 @@ struct CompositeArgs {
 __device__ void composite_reduce_body(const float* partials, int N, float* scalars, int32_t* err, const CompositeArgs& a, int tid, int nthreads,
                                       double (*red)[5]);
 
+// lane l <- lane l+1 (wave_shl:1); lane 63 keeps `ident`
+__device__ __forceinline__ float dpp_next_f(float ident, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, ident), __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+}
+// exclusive prefix product over the ray, registers in / out: lane l holds samples [l C, (l+1) C) - wave_scan<true>'s arithmetic on the same chunks
+template <int C>
+__device__ __forceinline__ void ray_prefix_prod(const float (&in)[C], const bool (&ok)[C], float (&out)[C]) {
+    double loc = 1.0;
+#pragma unroll
+    for (int i = 0; i < C; ++i) if (ok[i]) loc *= (double)in[i];
+    const double inc = wave_scan_incl_d<true>(loc);
+    double run = dpp_d<0x138, 0xf>(1.0, inc);
+#pragma unroll
+    for (int i = 0; i < C; ++i) { out[i] = (float)run; if (ok[i]) run *= (double)in[i]; }
+}
+
+// Round 5: the ray lives in registers (lane l = samples [l C, (l+1) C), C = 1, 2 or 4), one burst of loads, neighbours over DPP, no LDS and
+// no barriers - see composite_bwd_kernel.  Same expressions and the same scan chunks as the LDS version of rounds 1-4.
+template <int C>
 __global__ __launch_bounds__(64) void composite_kernel(const CompositeArgs a) {
-    __shared__ float s_z[MAXS], s_tc[MAXS], s_a[MAXS], s_b[MAXS], s_al[MAXS], s_occ[MAXS];
     const int ray = blockIdx.x, lane = threadIdx.x, S = a.S;
+    const size_t rb = (size_t)ray * S;
+    float z[C + 1], u[C], gx[C], gy[C], gz[C], tc[C + 1];
+    bool ok[C], last[C];
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+        const int e = lane * C + i;
+        ok[i] = e < S; last[i] = !(e < S - 1);
+        const size_t q = rb + (ok[i] ? e : S - 1);
+        z[i] = a.z[q]; u[i] = a.udf[q];
+        gx[i] = a.grad[3 * q]; gy[i] = a.grad[3 * q + 1]; gz[i] = a.grad[3 * q + 2];
+    }
     const float ox = a.rays_o[3 * ray], oy = a.rays_o[3 * ray + 1], oz = a.rays_o[3 * ray + 2];
     const float dx = a.rays_d[3 * ray], dy = a.rays_d[3 * ray + 1], dz = a.rays_d[3 * ray + 2];
     const float sd = *a.sample_dist;
@@ -422,73 +451,65 @@ __global__ __launch_bounds__(64) void composite_kernel(const CompositeArgs a) {
         beta_ = clipf(clipf(expf(FMUL(a.beta_p[0], 10.0f)), 0.0f, FDIV(1.0f, a.beta_min)), 1e-6f, 1e6f);
         gamma_ = clipf(expf(FMUL(a.gamma_p[0], 10.0f)), 1e-6f, 1e6f);
     }
-    const size_t rb = (size_t)ray * S;
-    for (int e = lane; e < S; e += 64) s_z[e] = a.z[rb + e];
-    __syncthreads();
-    // pass 1: true_cos and alpha_occ
-    for (int e = lane; e < S; e += 64) {
-        const float gx = a.grad[3 * (rb + e)], gy = a.grad[3 * (rb + e) + 1], gz = a.grad[3 * (rb + e) + 2];
-        s_tc[e] = FADD(FADD(FMUL(dx, gx), FMUL(dy, gy)), FMUL(dz, gz));                 // :482
-        const float dists = (e < S - 1) ? FSUB(s_z[e + 1], s_z[e]) : sd;                // :435-444
-        const float raw_occ = udf2logistic1(a.udf[rb + e], beta_);                      // :492
-        s_occ[e] = FSUB(1.0f, expf(FMUL(FMUL(-relu_(raw_occ), gamma_), dists)));        // :497
+#pragma unroll
+    for (int i = 0; i < C; ++i) tc[i] = FADD(FADD(FMUL(dx, gx[i]), FMUL(dy, gy[i])), FMUL(dz, gz[i]));      // :482
+    z[C] = dpp_next_f(0.f, z[0]);       // sample e+1 of a lane's last sample is the next lane's first
+    tc[C] = dpp_next_f(0.f, tc[0]);
+    float dists[C], av[C], sb[C];
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+        dists[i] = last[i] ? sd : FSUB(z[i + 1], z[i]);                                 // :435-444
+        const float raw_occ = udf2logistic1(u[i], beta_);                               // :492
+        const float occ = FSUB(1.0f, expf(FMUL(FMUL(-relu_(raw_occ), gamma_), dists[i])));   // :497
+        const float vis_mask = last[i] ? 1.0f : ((tc[i + 1] < 0.01f) ? 1.0f : 0.0f);    // :500-509
+        av[i] = FADD(clipf(FADD(FSUB(1.0f, occ), FMUL(a.flip_sat, vis_mask)), 0.0f, 1.0f), 1e-7f);  // :515
     }
-    __syncthreads();
-    for (int e = lane; e < S; e += 64) {
-        const float vis_mask = (e < S - 1) ? ((s_tc[e + 1] < 0.01f) ? 1.0f : 0.0f) : 1.0f;  // :500-509
-        s_a[e] = FADD(clipf(FADD(FSUB(1.0f, s_occ[e]), FMUL(a.flip_sat, vis_mask)), 0.0f, 1.0f), 1e-7f);  // :515
+    ray_prefix_prod<C>(av, ok, sb);     // vis_prob (:511-523)
+    float alpha[C];
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+        const float vp = clipf(sb[i], 0.0f, 1.0f);                                      // :528
+        const float tcn = -fabsf(tc[i]);
+        const float ap = sdf2alpha(u[i], tcn, dists[i], inv_s_, a.anneal != 0, a.car);  // :530-543
+        const float am = sdf2alpha(-u[i], tcn, dists[i], inv_s_, a.anneal != 0, a.car);
+        alpha[i] = FADD(FMUL(ap, vp), FMUL(am, FSUB(1.0f, vp)));                        // :545
+        av[i] = FADD(FSUB(1.0f, alpha[i]), 1e-7f);
     }
-    __syncthreads();
-    wave_scan<true>(s_a, s_b, S, lane);  // vis_prob (:511-523)
-    __syncthreads();
-    for (int e = lane; e < S; e += 64) {
-        const float vp = clipf(s_b[e], 0.0f, 1.0f);                                     // :528
-        const float dists = (e < S - 1) ? FSUB(s_z[e + 1], s_z[e]) : sd;
-        const float u = a.udf[rb + e];
-        const float tc = -fabsf(s_tc[e]);
-        const float ap = sdf2alpha(u, tc, dists, inv_s_, a.anneal != 0, a.car);         // :530-543
-        const float am = sdf2alpha(-u, tc, dists, inv_s_, a.anneal != 0, a.car);
-        const float alpha = FADD(FMUL(ap, vp), FMUL(am, FSUB(1.0f, vp)));               // :545
-        s_al[e] = alpha;
-        s_a[e] = FADD(FSUB(1.0f, alpha), 1e-7f);
-    }
-    __syncthreads();
-    wave_scan<true>(s_a, s_b, S, lane);  // transmittance (:593-602)
-    __syncthreads();
+    ray_prefix_prod<C>(av, ok, sb);     // transmittance (:593-602)
     double wsum = 0, dsum = 0, nx = 0, ny = 0, nz = 0, e_rel = 0, c_rel = 0, e_ns = 0, c_ns = 0, sp = 0;
-    for (int e = lane; e < S; e += 64) {
-        const float alpha = s_al[e];
-        const float w = FMUL(alpha, s_b[e]);
-        const float dists = (e < S - 1) ? FSUB(s_z[e + 1], s_z[e]) : sd;
-        const float mid = FADD(s_z[e], FMUL(dists, 0.5f));                              // :446
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+        const float w = FMUL(alpha[i], sb[i]);
+        const float mid = FADD(z[i], FMUL(dists[i], 0.5f));                             // :446
         const float px = FADD(ox, FMUL(dx, mid)), py = FADD(oy, FMUL(dy, mid)), pz = FADD(oz, FMUL(dz, mid));
         const float pn = sqrtf(FADD(FADD(FMUL(px, px), FMUL(py, py)), FMUL(pz, pz)));   // :563
-        const float gx = a.grad[3 * (rb + e)], gy = a.grad[3 * (rb + e) + 1], gz = a.grad[3 * (rb + e) + 2];
-        const float gm = sqrtf(FADD(FADD(FMUL(gx, gx), FMUL(gy, gy)), FMUL(gz, gz)));   // :463
+        const float gm = sqrtf(FADD(FADD(FMUL(gx[i], gx[i]), FMUL(gy[i], gy[i])), FMUL(gz[i], gz[i])));   // :463
         const float gi = FADD(gm, 1e-5f);
-        const float cosn = FADD(FADD(FMUL(dx, FDIV(gx, gi)), FMUL(dy, FDIV(gy, gi))), FMUL(dz, FDIV(gz, gi)));  // :485
-        float flip = (cosn > 0.f) ? -1.0f : ((cosn < 0.f) ? 1.0f : 1.0f);               // :486-489
-        const float u = a.udf[rb + e];
+        const float cosn = FADD(FADD(FMUL(dx, FDIV(gx[i], gi)), FMUL(dy, FDIV(gy[i], gi))), FMUL(dz, FDIV(gz[i], gi)));  // :485
+        const float flip = (cosn > 0.f) ? -1.0f : 1.0f;                                 // :486-489
         const float inside = (pn < 2.0f) ? 1.0f : 0.0f, relax = (pn < 2.4f) ? 1.0f : 0.0f;  // :568-569
-        const float ns = (u < a.near_surface) ? 1.0f : 0.0f;                            // :570
+        const float ns = (u[i] < a.near_surface) ? 1.0f : 0.0f;                         // :570
         const float ge = FMUL(FSUB(gm, 1.0f), FSUB(gm, 1.0f));                          // :612-617
-        if (a.out.weights) a.out.weights[rb + e] = w;
-        if (a.out.alpha) a.out.alpha[rb + e] = alpha;
-        if (a.out.mid_z) a.out.mid_z[rb + e] = mid;
-        if (a.out.dists) a.out.dists[rb + e] = dists;
-        if (a.out.inside_sphere) a.out.inside_sphere[rb + e] = inside;
-        if (a.out.gradient_mag) a.out.gradient_mag[rb + e] = gm;
-        if (a.out.gradients_flip) {
-            a.out.gradients_flip[3 * (rb + e)] = FMUL(flip, gx);
-            a.out.gradients_flip[3 * (rb + e) + 1] = FMUL(flip, gy);
-            a.out.gradients_flip[3 * (rb + e) + 2] = FMUL(flip, gz);
+        if (ok[i]) {
+            const size_t q = rb + lane * C + i;
+            if (a.out.weights) a.out.weights[q] = w;
+            if (a.out.alpha) a.out.alpha[q] = alpha[i];
+            if (a.out.mid_z) a.out.mid_z[q] = mid;
+            if (a.out.dists) a.out.dists[q] = dists[i];
+            if (a.out.inside_sphere) a.out.inside_sphere[q] = inside;
+            if (a.out.gradient_mag) a.out.gradient_mag[q] = gm;
+            if (a.out.gradients_flip) {
+                a.out.gradients_flip[3 * q] = FMUL(flip, gx[i]);
+                a.out.gradients_flip[3 * q + 1] = FMUL(flip, gy[i]);
+                a.out.gradients_flip[3 * q + 2] = FMUL(flip, gz[i]);
+            }
+            wsum += w;
+            dsum += (double)FMUL(mid, w);
+            nx += (double)FMUL(FMUL(flip, gx[i]), w); ny += (double)FMUL(FMUL(flip, gy[i]), w); nz += (double)FMUL(FMUL(flip, gz[i]), w);
+            e_rel += (double)FMUL(relax, ge); c_rel += relax;
+            e_ns += (double)FMUL(ns, ge); c_ns += ns;
+            sp += (double)expf(FMUL(-a.sparse_scale, u[i]));                            // :642-644
         }
-        wsum += w;
-        dsum += (double)FMUL(mid, w);
-        nx += (double)FMUL(FMUL(flip, gx), w); ny += (double)FMUL(FMUL(flip, gy), w); nz += (double)FMUL(FMUL(flip, gz), w);
-        e_rel += (double)FMUL(relax, ge); c_rel += relax;
-        e_ns += (double)FMUL(ns, ge); c_ns += ns;
-        sp += (double)expf(FMUL(-a.sparse_scale, u));                                   // :642-644
     }
     wsum = wave_sum_d(wsum); dsum = wave_sum_d(dsum);
     nx = wave_sum_d(nx); ny = wave_sum_d(ny); nz = wave_sum_d(nz);
@@ -560,46 +581,12 @@ __global__ __launch_bounds__(256) void composite_reduce_kernel(const float* part
 // torch.autograd through the oracle) is oracle/vjp_mirror.py:composite_bwd / tests/test_vjp_math.py.  One wave per ray;
 // the forward quantities are recomputed with the forward kernel's own expressions so that every clip / mask decision is
 // the one the forward took; the two cumprod adjoints are exclusive suffix sums (fp64 wave scans).
-__device__ __forceinline__ void wave_suffix_sum(const float* in, float* out, int n, int lane) {   // out[e] = sum_{k>e} in[k]
-    const int C = (n + 63) >> 6;
-    const int b = lane * C;       // chunk of REVERSED indices
-    double loc = 0.0;
-    for (int i = 0; i < C; ++i) { const int e = b + i; if (e < n) loc += (double)in[n - 1 - e]; }
-    double inc = loc;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const double o = __shfl_up(inc, off);
-        if (lane >= off) inc += o;
-    }
-    double run = __shfl_up(inc, 1);
-    if (lane == 0) run = 0.0;
-    for (int i = 0; i < C; ++i) {
-        const int e = b + i;
-        if (e < n) { out[n - 1 - e] = (float)run; run += (double)in[n - 1 - e]; }
-    }
-}
-
-// backward of sdf2alpha(sdf, -tabs, dists, inv_s) for an upstream gradient dval on its clipped output
-__device__ __forceinline__ void sdf2alpha_bwd(float sdf, float tabs, float dists, float inv_s, bool anneal, float car, float dval,
-                                              float& d_sdf, float& d_tabs, float& d_inv_s) {
-    float ic = -tabs, dic = -1.0f;
-    if (anneal) {
-        ic = -((0.5f * tabs + 0.5f) * (1.0f - car) + tabs * car);
-        dic = -(0.5f * (1.0f - car) + ((tabs > 0.f) ? car : 0.f));
-    }
-    const float hh = ic * dists * 0.5f;
-    const float en = sdf + hh, ep = sdf - hh;
-    const float pc = sigmoidf_(ep * inv_s), nc = sigmoidf_(en * inv_s);
-    const float den = pc + 1e-5f;
-    const float val = (pc - nc + 1e-5f) / den;
-    const float dv = (val >= 0.f && val <= 1.f) ? dval : 0.f;
-    const float dpc = dv * nc / (den * den), dnc = -dv / den;
-    const float gp = dpc * pc * (1.0f - pc), gn = dnc * nc * (1.0f - nc);
-    d_inv_s = gp * ep + gn * en;
-    d_sdf = (gp + gn) * inv_s;
-    d_tabs = (gn - gp) * inv_s * dists * 0.5f * dic;
-}
-
+//
+// Round 5: the ray lives in REGISTERS - lane l holds the C = 1, 2 or 4 consecutive samples [l C, (l+1) C) (the chunking wave_scan uses,
+// so the two prefix products are bit-identical to the forward kernel's), every input is fetched by one burst of loads at the top (one
+// memory round trip instead of one per pass and loop iteration), neighbours (z, true_cos of sample e+1) come over the DPP network, and
+// the sigmoids / exponentials of the forward recomputation are kept for the adjoint instead of being evaluated a second time.  No LDS,
+// no barriers.  The round-4 kernel (13 LDS arrays per ray, strided passes) took 24 us at 512 rays and 108 us at 4096.
 struct CompositeBwdArgs {
     const float *rays_o, *rays_d, *z, *udf, *grad, *depth_scale, *sample_dist;
     int N, S;
@@ -614,16 +601,75 @@ struct CompositeBwdArgs {
     const float* scalars;               // the forward's scalars: [4] = sum(relax), [6] = sum(near)
     float *d_udf, *d_grad;              // (N,S), (N,S,3)
     float* partials;                    // (N,4): per-ray d_inv_s, d_beta, d_gamma
-    uint32_t* absmax;                   // [2]: max|d_udf|, max|d_grad| (atomicMax), may be null
+    uint32_t* absmax;                   // [2]: max|d_udf|, max|d_grad| of the launch, written by the reduce kernel; may be null
+    float* raymax;                      // (N,2): the per-ray maxima behind them (null iff absmax is)
 };
 
-// MS = capacity of the 13 per-ray LDS arrays: 128 for S <= 128 (6.5 KiB per ray: 24 rays resident per CU instead of 12), else 256.  Measured at
-// 4096 rays (16 per CU): 108.6 us either way - with four rays per SIMD the kernel is bound by its instruction count, not by residency (round 4)
-template <int MS>
+// lane l <- lane 63 - l
+__device__ __forceinline__ double lane_reverse_d(double v, int lane) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const int idx = (63 - lane) << 2;
+    const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(idx, (int)(unsigned)b), hi = (unsigned)__builtin_amdgcn_ds_bpermute(idx, (int)(unsigned)(b >> 32));
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+// exclusive suffix sum over the ray: out[e] = sum_{k>e} in[k]; the lanes are reversed around the forward DPP scan
+template <int C>
+__device__ __forceinline__ void ray_suffix_sum(const float (&in)[C], const bool (&ok)[C], float (&out)[C], int lane) {
+    double loc = 0.0;
+#pragma unroll
+    for (int i = C - 1; i >= 0; --i) if (ok[i]) loc += (double)in[i];
+    const double inc = wave_scan_incl_d<false>(lane_reverse_d(loc, lane));
+    double run = lane_reverse_d(dpp_d<0x138, 0xf>(0.0, inc), lane);
+#pragma unroll
+    for (int i = C - 1; i >= 0; --i) { out[i] = (float)run; if (ok[i]) run += (double)in[i]; }
+}
+
+// sdf2alpha (the forward's expressions, bit for bit) that also hands back what its adjoint needs
+struct Sdf2AlphaKeep { float val, pc, nc, den, en, ep; };
+__device__ __forceinline__ float sdf2alpha_keep(float sdf, float true_cos, float dists, float inv_s, bool anneal, float car, Sdf2AlphaKeep& k) {
+    float iter_cos = true_cos;
+    if (anneal) {
+        const float a = FMUL(relu_(FADD(FMUL(-true_cos, 0.5f), 0.5f)), FSUB(1.0f, car));
+        const float b = FMUL(relu_(-true_cos), car);
+        iter_cos = -FADD(a, b);
+    }
+    const float h = FMUL(FMUL(iter_cos, dists), 0.5f);
+    k.en = FADD(sdf, h);
+    k.ep = FSUB(sdf, h);
+    k.pc = sigmoidf_(FMUL(k.ep, inv_s));
+    k.nc = sigmoidf_(FMUL(k.en, inv_s));
+    k.den = FADD(k.pc, 1e-5f);
+    k.val = FDIV(FADD(FSUB(k.pc, k.nc), 1e-5f), k.den);
+    return clipf(k.val, 0.0f, 1.0f);
+}
+// backward of sdf2alpha(sdf, -tabs, dists, inv_s) for an upstream gradient dval on its clipped output
+__device__ __forceinline__ void sdf2alpha_bwd(const Sdf2AlphaKeep& k, float tabs, float dists, float inv_s, bool anneal, float car, float dval,
+                                              float& d_sdf, float& d_tabs, float& d_inv_s) {
+    const float dic = anneal ? -(0.5f * (1.0f - car) + ((tabs > 0.f) ? car : 0.f)) : -1.0f;
+    const float rden = __builtin_amdgcn_rcpf(k.den);
+    const float dv = (k.val >= 0.f && k.val <= 1.f) ? dval : 0.f;
+    const float dnc = -dv * rden, dpc = dv * k.nc * rden * rden;
+    const float gp = dpc * k.pc * (1.0f - k.pc), gn = dnc * k.nc * (1.0f - k.nc);
+    d_inv_s = gp * k.ep + gn * k.en;
+    d_sdf = (gp + gn) * inv_s;
+    d_tabs = (gn - gp) * inv_s * dists * 0.5f * dic;
+}
+
+template <int C>
 __global__ __launch_bounds__(64) void composite_bwd_kernel(const CompositeBwdArgs a) {
-    __shared__ float s_z[MS], s_tc[MS], s_eq[MS], s_ain[MS], s_a[MS], s_vp[MS], s_ap[MS], s_am[MS], s_om[MS],
-        s_T[MS], s_x[MS], s_suf[MS], s_dal[MS];
     const int ray = blockIdx.x, lane = threadIdx.x, S = a.S;
+    const size_t rb = (size_t)ray * S;
+    // one burst: the ray's samples (clamped to the last one past the end), then the per-ray and per-launch scalars
+    float z[C + 1], u[C], gx[C], gy[C], gz[C], tc[C + 1];
+    bool ok[C], last[C];
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+        const int e = lane * C + i;
+        ok[i] = e < S; last[i] = !(e < S - 1);
+        const size_t q = rb + (ok[i] ? e : S - 1);
+        z[i] = a.z[q]; u[i] = a.udf[q];
+        gx[i] = a.grad[3 * q]; gy[i] = a.grad[3 * q + 1]; gz[i] = a.grad[3 * q + 2];
+    }
     const float ox = a.rays_o[3 * ray], oy = a.rays_o[3 * ray + 1], oz = a.rays_o[3 * ray + 2];
     const float dx = a.rays_d[3 * ray], dy = a.rays_d[3 * ray + 1], dz = a.rays_d[3 * ray + 2];
     const float sd = *a.sample_dist;
@@ -633,109 +679,93 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(const CompositeBwdArg
         beta_ = clipf(clipf(expf(FMUL(a.beta_p[0], 10.0f)), 0.0f, FDIV(1.0f, a.beta_min)), 1e-6f, 1e6f);
         gamma_ = clipf(expf(FMUL(a.gamma_p[0], 10.0f)), 1e-6f, 1e6f);
     }
-    const size_t rb = (size_t)ray * S;
     const float g_edge = a.d_edge ? a.d_edge[ray] * (a.has_bg ? (1.0f - a.background) : 1.0f) : 0.f;
     const float g_depth = a.d_depth ? a.d_depth[ray] * (a.depth_scale ? a.depth_scale[ray] : 1.0f) : 0.f;
     const float c_ge = a.d_ge ? a.d_ge[0] / (a.scalars[4] + 1e-5f) : 0.f;
     const float c_ns = a.d_ge_ns ? a.d_ge_ns[0] / (a.scalars[6] + 1e-5f) : 0.f;
-    for (int e = lane; e < S; e += 64) s_z[e] = a.z[rb + e];
-    __syncthreads();
-    for (int e = lane; e < S; e += 64) {
-        const float gx = a.grad[3 * (rb + e)], gy = a.grad[3 * (rb + e) + 1], gz = a.grad[3 * (rb + e) + 2];
-        s_tc[e] = FADD(FADD(FMUL(dx, gx), FMUL(dy, gy)), FMUL(dz, gz));
-        const float dists = (e < S - 1) ? FSUB(s_z[e + 1], s_z[e]) : sd;
-        const float raw_occ = udf2logistic1(a.udf[rb + e], beta_);
-        s_eq[e] = expf(FMUL(FMUL(-relu_(raw_occ), gamma_), dists));            // 1 - alpha_occ up to rounding
+    const bool anneal = a.anneal != 0;
+
+#pragma unroll
+    for (int i = 0; i < C; ++i) tc[i] = FADD(FADD(FMUL(dx, gx[i]), FMUL(dy, gy[i])), FMUL(dz, gz[i]));
+    z[C] = dpp_next_f(0.f, z[0]);       // sample e+1 of a lane's last sample is the next lane's first
+    tc[C] = dpp_next_f(0.f, tc[0]);
+    float dists[C], E[C], opE[C], raw[C], eq[C], ain[C], av[C], vpr[C];
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+        dists[i] = last[i] ? sd : FSUB(z[i + 1], z[i]);
+        E[i] = expf(FMUL(-beta_, u[i]));                        // udf2logistic1(u, beta) with its pieces kept
+        opE[i] = FADD(1.0f, E[i]);
+        raw[i] = FDIV(FMUL(beta_, E[i]), FMUL(opE[i], opE[i]));
+        eq[i] = expf(FMUL(FMUL(-relu_(raw[i]), gamma_), dists[i]));            // 1 - alpha_occ up to rounding
+        const float vis_mask = last[i] ? 1.0f : ((tc[i + 1] < 0.01f) ? 1.0f : 0.0f);
+        const float occ = FSUB(1.0f, eq[i]);
+        ain[i] = FADD(FSUB(1.0f, occ), FMUL(a.flip_sat, vis_mask));
+        av[i] = FADD(clipf(ain[i], 0.0f, 1.0f), 1e-7f);
     }
-    __syncthreads();
-    for (int e = lane; e < S; e += 64) {
-        const float vis_mask = (e < S - 1) ? ((s_tc[e + 1] < 0.01f) ? 1.0f : 0.0f) : 1.0f;
-        const float occ = FSUB(1.0f, s_eq[e]);
-        const float ain = FADD(FSUB(1.0f, occ), FMUL(a.flip_sat, vis_mask));
-        s_ain[e] = ain;
-        s_a[e] = FADD(clipf(ain, 0.0f, 1.0f), 1e-7f);
+    ray_prefix_prod<C>(av, ok, vpr);           // raw (unclipped) visibility product
+    Sdf2AlphaKeep kp[C], km[C];
+    float ap[C], am[C], vp[C], alpha[C], om[C], T[C];
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+        vp[i] = clipf(vpr[i], 0.0f, 1.0f);
+        const float tcn = -fabsf(tc[i]);
+        ap[i] = sdf2alpha_keep(u[i], tcn, dists[i], inv_s_, anneal, a.car, kp[i]);
+        am[i] = sdf2alpha_keep(-u[i], tcn, dists[i], inv_s_, anneal, a.car, km[i]);
+        alpha[i] = FADD(FMUL(ap[i], vp[i]), FMUL(am[i], FSUB(1.0f, vp[i])));
+        om[i] = FADD(FSUB(1.0f, alpha[i]), 1e-7f);
     }
-    __syncthreads();
-    wave_scan<true>(s_a, s_vp, S, lane);       // raw (unclipped) visibility product
-    __syncthreads();
-    for (int e = lane; e < S; e += 64) {
-        const float vp = clipf(s_vp[e], 0.0f, 1.0f);
-        const float dists = (e < S - 1) ? FSUB(s_z[e + 1], s_z[e]) : sd;
-        const float u = a.udf[rb + e];
-        const float tc = -fabsf(s_tc[e]);
-        const float ap = sdf2alpha(u, tc, dists, inv_s_, a.anneal != 0, a.car);
-        const float am = sdf2alpha(-u, tc, dists, inv_s_, a.anneal != 0, a.car);
-        const float alpha = FADD(FMUL(ap, vp), FMUL(am, FSUB(1.0f, vp)));
-        s_ap[e] = ap; s_am[e] = am;
-        s_om[e] = FADD(FSUB(1.0f, alpha), 1e-7f);
+    ray_prefix_prod<C>(om, ok, T);             // transmittance
+    float mid[C], dal[C], x[C], suf[C];
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+        mid[i] = FADD(z[i], FMUL(dists[i], 0.5f));
+        dal[i] = g_edge + g_depth * mid[i];                     // dL/dw_e for now
+        x[i] = dal[i] * alpha[i] * T[i];                        // dw_e * w_e
     }
-    __syncthreads();
-    wave_scan<true>(s_om, s_T, S, lane);       // transmittance
-    __syncthreads();
-    for (int e = lane; e < S; e += 64) {
-        const float vp = clipf(s_vp[e], 0.0f, 1.0f);
-        const float alpha = FADD(FMUL(s_ap[e], vp), FMUL(s_am[e], FSUB(1.0f, vp)));
-        const float dists = (e < S - 1) ? FSUB(s_z[e + 1], s_z[e]) : sd;
-        const float mid = FADD(s_z[e], FMUL(dists, 0.5f));
-        const float dw = g_edge + g_depth * mid;
-        s_dal[e] = dw;                          // dL/dw_e for now
-        s_x[e] = dw * alpha * s_T[e];           // dw_e * w_e
+    ray_suffix_sum<C>(x, ok, suf, lane);
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+        dal[i] = dal[i] * T[i] - suf[i] * __builtin_amdgcn_rcpf(om[i]);
+        const float dvp = (vpr[i] >= 0.f && vpr[i] <= 1.f) ? dal[i] * (ap[i] - am[i]) : 0.f;
+        x[i] = dvp * vpr[i];
     }
-    __syncthreads();
-    wave_suffix_sum(s_x, s_suf, S, lane);
-    __syncthreads();
-    for (int e = lane; e < S; e += 64) {
-        const float dalpha = s_dal[e] * s_T[e] - s_suf[e] / s_om[e];
-        s_dal[e] = dalpha;
-        const float vr = s_vp[e];
-        const float dvp = (vr >= 0.f && vr <= 1.f) ? dalpha * (s_ap[e] - s_am[e]) : 0.f;
-        s_x[e] = dvp * vr;
-    }
-    __syncthreads();
-    wave_suffix_sum(s_x, s_suf, S, lane);
-    __syncthreads();
+    ray_suffix_sum<C>(x, ok, suf, lane);
     double p_is = 0.0, p_beta = 0.0, p_gamma = 0.0;
     float mx_u = 0.f, mx_g = 0.f;
-    for (int e = lane; e < S; e += 64) {
-        const float dists = (e < S - 1) ? FSUB(s_z[e + 1], s_z[e]) : sd;
-        const float mid = FADD(s_z[e], FMUL(dists, 0.5f));
-        const float u = a.udf[rb + e];
-        const float gx = a.grad[3 * (rb + e)], gy = a.grad[3 * (rb + e) + 1], gz = a.grad[3 * (rb + e) + 2];
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
         // occlusion branch: a_i = clip(1 - occ + fs*vm) + 1e-7
-        const float da = s_suf[e] / s_a[e];
-        const float docc = (s_ain[e] >= 0.f && s_ain[e] <= 1.f) ? -da : 0.f;
-        const float dq = docc * s_eq[e];
-        const float E = expf(-beta_ * u);
-        const float opE = 1.0f + E;
-        const float raw = beta_ * E / (opE * opE);
-        const float draw = (raw > 0.f) ? dq * gamma_ * dists : 0.f;
-        p_gamma += (double)(dq * relu_(raw) * dists);
-        const float fE = (1.0f - E) / (opE * opE * opE);
-        float du = draw * (-beta_ * beta_ * E * fE);
-        p_beta += (double)(draw * (E / (opE * opE) - beta_ * u * E * fE));
+        const float da = suf[i] * __builtin_amdgcn_rcpf(av[i]);
+        const float docc = (ain[i] >= 0.f && ain[i] <= 1.f) ? -da : 0.f;
+        const float dq = docc * eq[i];
+        const float r1 = __builtin_amdgcn_rcpf(opE[i]), r2 = r1 * r1;
+        const float draw = (raw[i] > 0.f) ? dq * gamma_ * dists[i] : 0.f;
+        const float fE = (1.0f - E[i]) * r2 * r1;
+        float du = draw * (-beta_ * beta_ * E[i] * fE);
+        const float pb = draw * (E[i] * r2 - beta_ * u[i] * E[i] * fE), pg = dq * relu_(raw[i]) * dists[i];
         // alpha branch
-        const float vp = clipf(s_vp[e], 0.0f, 1.0f);
-        const float dalpha = s_dal[e];
-        const float tabs = fabsf(s_tc[e]);
+        const float tabs = fabsf(tc[i]);
         float s1, t1, i1, s2, t2, i2;
-        sdf2alpha_bwd(u, tabs, dists, inv_s_, a.anneal != 0, a.car, dalpha * vp, s1, t1, i1);
-        sdf2alpha_bwd(-u, tabs, dists, inv_s_, a.anneal != 0, a.car, dalpha * (1.0f - vp), s2, t2, i2);
+        sdf2alpha_bwd(kp[i], tabs, dists[i], inv_s_, anneal, a.car, dal[i] * vp[i], s1, t1, i1);
+        sdf2alpha_bwd(km[i], tabs, dists[i], inv_s_, anneal, a.car, dal[i] * (1.0f - vp[i]), s2, t2, i2);
         du += s1 - s2;
-        p_is += (double)(i1 + i2);
-        const float tcv = s_tc[e];
-        const float dtc = (t1 + t2) * ((tcv > 0.f) ? 1.f : ((tcv < 0.f) ? -1.f : 0.f));
+        const float dtc = (t1 + t2) * ((tc[i] > 0.f) ? 1.f : ((tc[i] < 0.f) ? -1.f : 0.f));
         // eikonal terms (:612-625), masks detached
-        const float px = FADD(ox, FMUL(dx, mid)), py = FADD(oy, FMUL(dy, mid)), pz = FADD(oz, FMUL(dz, mid));
+        const float px = FADD(ox, FMUL(dx, mid[i])), py = FADD(oy, FMUL(dy, mid[i])), pz = FADD(oz, FMUL(dz, mid[i]));
         const float pn = sqrtf(FADD(FADD(FMUL(px, px), FMUL(py, py)), FMUL(pz, pz)));
-        const float gm = sqrtf(FADD(FADD(FMUL(gx, gx), FMUL(gy, gy)), FMUL(gz, gz)));
-        const float relax = (pn < 2.4f) ? 1.0f : 0.0f, ns = (u < a.near_surface) ? 1.0f : 0.0f;
-        const float coef = (gm > 0.f) ? (c_ge * relax + c_ns * ns) * 2.0f * (gm - 1.0f) / gm : 0.f;
-        const float ogx = dtc * dx + coef * gx, ogy = dtc * dy + coef * gy, ogz = dtc * dz + coef * gz;
-        a.d_udf[rb + e] = du;
-        a.d_grad[3 * (rb + e)] = ogx; a.d_grad[3 * (rb + e) + 1] = ogy; a.d_grad[3 * (rb + e) + 2] = ogz;
-        const float au = fabsf(du), ag = fmaxf(fmaxf(fabsf(ogx), fabsf(ogy)), fabsf(ogz));
-        mx_u = (au < 3.0e38f) ? fmaxf(mx_u, au) : mx_u;
-        mx_g = (ag < 3.0e38f) ? fmaxf(mx_g, ag) : mx_g;
+        const float gm = sqrtf(FADD(FADD(FMUL(gx[i], gx[i]), FMUL(gy[i], gy[i])), FMUL(gz[i], gz[i])));
+        const float relax = (pn < 2.4f) ? 1.0f : 0.0f, ns = (u[i] < a.near_surface) ? 1.0f : 0.0f;
+        const float coef = (gm > 0.f) ? (c_ge * relax + c_ns * ns) * 2.0f * (gm - 1.0f) * __builtin_amdgcn_rcpf(gm) : 0.f;
+        const float ogx = dtc * dx + coef * gx[i], ogy = dtc * dy + coef * gy[i], ogz = dtc * dz + coef * gz[i];
+        if (ok[i]) {
+            const size_t q = rb + lane * C + i;
+            a.d_udf[q] = du;
+            a.d_grad[3 * q] = ogx; a.d_grad[3 * q + 1] = ogy; a.d_grad[3 * q + 2] = ogz;
+            p_is += (double)(i1 + i2); p_beta += (double)pb; p_gamma += (double)pg;
+            const float au = fabsf(du), ag = fmaxf(fmaxf(fabsf(ogx), fabsf(ogy)), fabsf(ogz));
+            mx_u = (au < 3.0e38f) ? fmaxf(mx_u, au) : mx_u;
+            mx_g = (ag < 3.0e38f) ? fmaxf(mx_g, ag) : mx_g;
+        }
     }
     p_is = wave_sum_d(p_is); p_beta = wave_sum_d(p_beta); p_gamma = wave_sum_d(p_gamma);
 #pragma unroll
@@ -743,10 +773,9 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(const CompositeBwdArg
     if (lane == 0) {
         float* p = a.partials + (size_t)ray * 4;
         p[0] = (float)p_is; p[1] = (float)p_beta; p[2] = (float)p_gamma; p[3] = 0.f;
-        if (a.absmax) {
-            atomicMax(a.absmax, __builtin_bit_cast(uint32_t, mx_u));
-            atomicMax(a.absmax + 1, __builtin_bit_cast(uint32_t, mx_g));
-        }
+        // the launch maxima are formed by the reduce kernel: two atomicMax per ray on one cache line cost 10.5 ns EACH, serialised in L2 -
+        // 11 of the kernel's 18 us at 512 rays, 85 of 100 us at 4096 (round 5, profiles/r05_composite_kernels.txt)
+        if (a.raymax) { a.raymax[2 * (size_t)ray] = mx_u; a.raymax[2 * (size_t)ray + 1] = mx_g; }
     }
 }
 
@@ -756,17 +785,29 @@ __global__ __launch_bounds__(256) void composite_bwd_reduce_kernel(const float* 
                                                                    float* d_variance, float* d_beta, float* d_gamma, float grad_scale,
                                                                    int accumulate) {
     __shared__ double red[4][3];
+    __shared__ float redm[4][2];
     double v[3] = {0, 0, 0};
-    for (int i = threadIdx.x; i < N; i += 256)
+    float mu = 0.f, mg = 0.f;       // per-ray maxima are finite and >= 0
+    for (int i = threadIdx.x; i < N; i += 256) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) v[k] += (double)partials[(size_t)i * 4 + k];
+        if (a.raymax) { mu = fmaxf(mu, a.raymax[2 * (size_t)i]); mg = fmaxf(mg, a.raymax[2 * (size_t)i + 1]); }
+    }
 #pragma unroll
     for (int k = 0; k < 3; ++k) v[k] = wave_sum_d(v[k]);
-    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { mu = fmaxf(mu, __shfl_xor(mu, off)); mg = fmaxf(mg, __shfl_xor(mg, off)); }
+    if ((threadIdx.x & 63) == 0) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) red[threadIdx.x >> 6][k] = v[k];
+        redm[threadIdx.x >> 6][0] = mu; redm[threadIdx.x >> 6][1] = mg;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
+        if (a.absmax) {
+            a.absmax[0] = __builtin_bit_cast(uint32_t, fmaxf(fmaxf(redm[0][0], redm[1][0]), fmaxf(redm[2][0], redm[3][0])));
+            a.absmax[1] = __builtin_bit_cast(uint32_t, fmaxf(fmaxf(redm[0][1], redm[1][1]), fmaxf(redm[2][1], redm[3][1])));
+        }
         double t[3];
         for (int k = 0; k < 3; ++k) t[k] = red[0][k] + red[1][k] + red[2][k] + red[3][k];
         float r_var = 0.f, r_beta = 0.f, r_gamma = 0.f;
@@ -875,7 +916,9 @@ int launch_composite(const float* rays_o, const float* rays_d, const float* z, c
     a.background = background; a.has_bg = has_bg; a.out = *out; a.partials = partials;
     a.var_p = var_p; a.beta_p = beta_p; a.gamma_p = gamma_p; a.beta_min = beta_min;
     if (var_p && (!beta_p || !gamma_p)) { set_error("composite: variance_dev given without beta_dev/gamma_dev"); return EMAP_E_INVALID; }
-    hipLaunchKernelGGL(composite_kernel, dim3(N), dim3(64), 0, st, a);
+    if (S <= 64) hipLaunchKernelGGL(composite_kernel<1>, dim3(N), dim3(64), 0, st, a);
+    else if (S <= 128) hipLaunchKernelGGL(composite_kernel<2>, dim3(N), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL(composite_kernel<4>, dim3(N), dim3(64), 0, st, a);
     if (out->scalars) hipLaunchKernelGGL(composite_reduce_kernel, dim3(1), dim3(256), 0, st, partials, N, out->scalars, err, a);
     return check_launch("composite");
 }
@@ -895,10 +938,11 @@ int launch_composite_bwd(const float* rays_o, const float* rays_d, const float* 
     if (a.var_p && (!a.beta_p || !a.gamma_p)) { set_error("composite_bwd: variance_dev given without beta_dev/gamma_dev"); return EMAP_E_INVALID; }
     a.d_edge = gr->d_edge; a.d_depth = gr->d_depth; a.d_ge = gr->d_gradient_error; a.d_ge_ns = gr->d_gradient_error_near_surface;
     a.scalars = gr->scalars; a.d_udf = d_udf; a.d_grad = d_grad3; a.partials = partials; a.absmax = absmax;
+    a.raymax = absmax ? partials + (size_t)N * 4 : nullptr;     // internal callers (emap_render_bwd) size `partials` as (N,4) + (N,2)
     if ((a.d_ge || a.d_ge_ns) && !a.scalars) { set_error("composite_bwd: the eikonal gradients need the forward's scalars"); return EMAP_E_INVALID; }
-    if (absmax && hipMemsetAsync(absmax, 0, 8, st) != hipSuccess) { set_error("hipMemsetAsync failed"); return EMAP_E_LAUNCH; }
-    if (S <= 128) hipLaunchKernelGGL(composite_bwd_kernel<128>, dim3(N), dim3(64), 0, st, a);
-    else hipLaunchKernelGGL(composite_bwd_kernel<MAXS>, dim3(N), dim3(64), 0, st, a);
+    if (S <= 64) hipLaunchKernelGGL(composite_bwd_kernel<1>, dim3(N), dim3(64), 0, st, a);
+    else if (S <= 128) hipLaunchKernelGGL(composite_bwd_kernel<2>, dim3(N), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL(composite_bwd_kernel<4>, dim3(N), dim3(64), 0, st, a);
     hipLaunchKernelGGL(composite_bwd_reduce_kernel, dim3(1), dim3(256), 0, st, partials, N, a, gr->d_variance, gr->d_beta,
                        gr->d_gamma, gr->grad_scale, gr->accumulate);
     return check_launch("composite_bwd");
