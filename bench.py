@@ -174,7 +174,7 @@ def train_key(dev, precision, rays, S, steps=40, warmup=10):
         smp = sampler.gen_random_rays_patches_at(None, rays, importance_sample=True)
         batch = {"rays_o": smp["rays"]["rays_o"], "rays_d": smp["rays"]["rays_v"], "near": near_f, "far": far_f,
                  "depth_scale": smp["depth_scale"], "cos_anneal_ratio": 1.0, "flip_saturation": 0.9,
-                 "t_rand": torch.rand(rays, 1, device=dev) - 0.5}
+                 "t_rand": smp["t_rand"]}
         return trainer.step(batch, smp["rays"]["edge"], n_rays_global=rays)
 
     for _ in range(warmup):
@@ -643,7 +643,7 @@ def main():
             smp = sampler.gen_random_rays_patches_at(None, rays, importance_sample=True)
             batch = {"rays_o": smp["rays"]["rays_o"], "rays_d": smp["rays"]["rays_v"], "near": near_f, "far": far_f,
                      "depth_scale": smp["depth_scale"], "cos_anneal_ratio": 1.0, "flip_saturation": 0.9,
-                     "t_rand": torch.rand(rays, 1, device=dev) - 0.5}
+                     "t_rand": smp["t_rand"]}       # the jitter of render() :719 comes with the rays (one device draw, no torch.rand launch)
             return trainer.step(batch, smp["rays"]["edge"], n_rays_global=rays * world)
     else:
         def eager_step():
@@ -667,13 +667,13 @@ def main():
                 smp0 = sampler.gen_random_rays_patches_at(None, rays, importance_sample=True)
                 batch0 = {"rays_o": smp0["rays"]["rays_o"], "rays_d": smp0["rays"]["rays_v"], "near": near_f, "far": far_f,
                           "depth_scale": smp0["depth_scale"], "cos_anneal_ratio": 1.0, "flip_saturation": 0.9,
-                          "t_rand": torch.rand(rays, 1, device=dev) - 0.5}
+                          "t_rand": smp0["t_rand"]}
                 replay = trainer.capture(batch0, smp0["rays"]["edge"], n_rays_global=rays * world, segmented=True)
 
                 def step():
                     smp = sampler.gen_random_rays_patches_at(None, rays, importance_sample=True)
                     return replay({"rays_o": smp["rays"]["rays_o"], "rays_d": smp["rays"]["rays_v"], "depth_scale": smp["depth_scale"],
-                                   "t_rand": torch.rand(rays, 1, device=dev) - 0.5}, smp["rays"]["edge"])
+                                   "t_rand": smp["t_rand"]}, smp["rays"]["edge"])
             elif a.mode == "train":
                 side = torch.cuda.Stream(device=dev)
                 side.wait_stream(torch.cuda.current_stream(dev))

@@ -23,7 +23,7 @@ PREC_F16X3E = 5    # f16x3 with f16 cross terms in both sweeps of the value+grad
 PRECISIONS = {"bf16": PREC_BF16, "bf16x3": PREC_BF16X3, "f16": PREC_F16, "f16x3": PREC_F16X3, "f16x3m": PREC_F16X3M, "f16x3e": PREC_F16X3E}
 UDF_TYPES = {"abs": 0, "square": 1, "sdf": 2}
 MAX_LIN = 12
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 F_NAN_SAMPLES = 1
 F_NAN_GRADERR = 2
@@ -53,7 +53,8 @@ class RenderParams(C.Structure):
 class CompositeGrads(C.Structure):
     _fields_ = [("d_edge", C.c_void_p), ("d_depth", C.c_void_p), ("d_gradient_error", C.c_void_p),
                 ("d_gradient_error_near_surface", C.c_void_p), ("scalars", C.c_void_p), ("d_variance", C.c_void_p),
-                ("d_beta", C.c_void_p), ("d_gamma", C.c_void_p), ("grad_scale", C.c_float), ("accumulate", C.c_int32)]
+                ("d_beta", C.c_void_p), ("d_gamma", C.c_void_p), ("grad_scale", C.c_float), ("accumulate", C.c_int32),
+                ("zero_tail", C.c_void_p), ("n_zero_tail", C.c_int64)]
 
 
 class ParamGrads(C.Structure):
@@ -69,7 +70,7 @@ class RayDataset(C.Structure):
 
 
 class RayBatch(C.Structure):
-    _fields_ = [(k, C.c_void_p) for k in ("rays_o", "rays_v", "edge", "depth_scale", "ndc_uv", "p_cam", "pixels", "img_idx")]
+    _fields_ = [(k, C.c_void_p) for k in ("rays_o", "rays_v", "edge", "depth_scale", "ndc_uv", "p_cam", "pixels", "img_idx", "t_rand")]
 
 
 # every symbol include/emap_hip.h declares: name -> (restype, argtypes)

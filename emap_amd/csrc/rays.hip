@@ -45,23 +45,37 @@ struct RayArgs {
     EmapRayBatch out;
     const int64_t* pixels_in;
     const uint64_t* counter;
+    uint64_t* bump;          // the counter again when THIS launch increments it (single-workgroup launches), else null
     uint64_t seed, offset;
     int32_t img_idx, batch, importance;
 };
 
-__global__ __launch_bounds__(256) void sample_rays_kernel(const RayArgs a) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= a.batch) return;
+__device__ __forceinline__ void sample_ray(const RayArgs& a, uint64_t step, int i);
+
+// batch <= 1024: ONE workgroup, which also increments the step counter once every lane has read it (a second launch for that cost 4.8 us of
+// a 6 us job); larger batches: 256-thread workgroups and bump_counter_kernel behind them
+__global__ __launch_bounds__(1024) void sample_rays_kernel(const RayArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t step = a.counter ? *a.counter : a.offset;
+    if (i < a.batch) sample_ray(a, step, i);
+    if (a.bump) {
+        __syncthreads();
+        if (threadIdx.x == 0) *a.bump = step + 1;
+    }
+}
+
+__device__ __forceinline__ void sample_ray(const RayArgs& a, uint64_t step, int i) {
     int img = a.img_idx;
     if (img < 0) img = a.ds.image_perm ? a.ds.image_perm[step % (uint64_t)a.ds.n_images] : (int)(step % (uint64_t)a.ds.n_images);
     const int H = a.ds.H, W = a.ds.W, HW = H * W;
     int px, py;
+    uint32_t r[4];
+    if (!a.pixels_in || a.out.t_rand) Philox::gen(a.seed, step, (uint64_t)i, r);
+    // render()'s per-ray jitter torch.rand([N,1]) - 0.5 (udf_renderer_blending.py:719) from word 2 of the ray's draw: U(-0.5, 0.5) on a 2^-24 grid
+    if (a.out.t_rand) a.out.t_rand[i] = (float)(r[2] >> 8) * (1.0f / 16777216.0f) - 0.5f;
     if (a.pixels_in) {
         px = (int)a.pixels_in[2 * i]; py = (int)a.pixels_in[2 * i + 1];
     } else {
-        uint32_t r[4];
-        Philox::gen(a.seed, step, (uint64_t)i, r);
         const int half = a.batch / 2;
         if (!a.importance || i < half) {                        // dataset.py:233-234 / 244-245
             px = rand_below(r[0], W); py = rand_below(r[1], H);
@@ -113,8 +127,13 @@ int launch_sample_rays(const EmapRayDataset* ds, int img_idx, int batch, int imp
     RayArgs a;
     a.ds = *ds; a.out = *out; a.pixels_in = pixels_in; a.counter = counter; a.seed = seed; a.offset = offset;
     a.img_idx = img_idx; a.batch = batch; a.importance = importance;
-    hipLaunchKernelGGL(sample_rays_kernel, dim3((batch + 255) / 256), dim3(256), 0, st, a);
-    if (counter) hipLaunchKernelGGL(bump_counter_kernel, dim3(1), dim3(1), 0, st, counter);
+    const bool one_wg = batch <= 1024;
+    a.bump = one_wg ? counter : nullptr;
+    if (one_wg) hipLaunchKernelGGL(sample_rays_kernel, dim3(1), dim3((batch + 63) / 64 * 64), 0, st, a);
+    else {
+        hipLaunchKernelGGL(sample_rays_kernel, dim3((batch + 255) / 256), dim3(256), 0, st, a);
+        if (counter) hipLaunchKernelGGL(bump_counter_kernel, dim3(1), dim3(1), 0, st, counter);
+    }
     return check_launch("sample_rays");
 }
 

@@ -603,6 +603,8 @@ struct CompositeBwdArgs {
     float* partials;                    // (N,4): per-ray d_inv_s, d_beta, d_gamma
     uint32_t* absmax;                   // [2]: max|d_udf|, max|d_grad| of the launch, written by the reduce kernel; may be null
     float* raymax;                      // (N,2): the per-ray maxima behind them (null iff absmax is)
+    float* zero_tail;                   // EmapCompositeGrads.zero_tail / n_zero_tail (cleared by the reduce kernel), or null
+    long long n_zero_tail;
 };
 
 // lane l <- lane 63 - l
@@ -786,6 +788,9 @@ __global__ __launch_bounds__(256) void composite_bwd_reduce_kernel(const float* 
                                                                    int accumulate) {
     __shared__ double red[4][3];
     __shared__ float redm[4][2];
+    if (a.zero_tail && !accumulate)      // before the three scalar gradients are written: they may lie inside the range
+        for (long long i = threadIdx.x; i < a.n_zero_tail; i += 256) a.zero_tail[i] = 0.f;
+    __syncthreads();
     double v[3] = {0, 0, 0};
     float mu = 0.f, mg = 0.f;       // per-ray maxima are finite and >= 0
     for (int i = threadIdx.x; i < N; i += 256) {
@@ -938,6 +943,7 @@ int launch_composite_bwd(const float* rays_o, const float* rays_d, const float* 
     if (a.var_p && (!a.beta_p || !a.gamma_p)) { set_error("composite_bwd: variance_dev given without beta_dev/gamma_dev"); return EMAP_E_INVALID; }
     a.d_edge = gr->d_edge; a.d_depth = gr->d_depth; a.d_ge = gr->d_gradient_error; a.d_ge_ns = gr->d_gradient_error_near_surface;
     a.scalars = gr->scalars; a.d_udf = d_udf; a.d_grad = d_grad3; a.partials = partials; a.absmax = absmax;
+    a.zero_tail = gr->n_zero_tail > 0 ? gr->zero_tail : nullptr; a.n_zero_tail = gr->n_zero_tail;
     a.raymax = absmax ? partials + (size_t)N * 4 : nullptr;     // internal callers (emap_render_bwd) size `partials` as (N,4) + (N,2)
     if ((a.d_ge || a.d_ge_ns) && !a.scalars) { set_error("composite_bwd: the eikonal gradients need the forward's scalars"); return EMAP_E_INVALID; }
     if (S <= 64) hipLaunchKernelGGL(composite_bwd_kernel<1>, dim3(N), dim3(64), 0, st, a);

@@ -79,13 +79,13 @@ class DeviceRaySampler:
             raise RuntimeError("emap_amd.DeviceRaySampler: the sampler kernel needs an MI355X (cuda) device; there is no CPU fallback "
                                "(the reference's own host sampler is Dataset.gen_random_rays_patches_at)")
         N = int(batch_size)
-        f = torch.empty(N * 13, dtype=torch.float32, device=dev)
-        rays_o, rays_v, edge, ds, uv, pc = f[:3 * N].view(N, 3), f[3 * N:6 * N].view(N, 3), f[6 * N:7 * N].view(N, 1), \
-            f[7 * N:8 * N].view(N, 1), f[8 * N:10 * N].view(N, 2), f[10 * N:13 * N].view(N, 3)
+        f = torch.empty(N * 14, dtype=torch.float32, device=dev)
+        rays_o, rays_v, edge, ds, uv, pc, tr = f[:3 * N].view(N, 3), f[3 * N:6 * N].view(N, 3), f[6 * N:7 * N].view(N, 1), \
+            f[7 * N:8 * N].view(N, 1), f[8 * N:10 * N].view(N, 2), f[10 * N:13 * N].view(N, 3), f[13 * N:].view(N, 1)
         pix = torch.empty(N, 2, dtype=torch.int64, device=dev)
         img = torch.empty(1, dtype=torch.int32, device=dev)
         out = _lib.RayBatch(rays_o.data_ptr(), rays_v.data_ptr(), edge.data_ptr(), ds.data_ptr(), uv.data_ptr(), pc.data_ptr(),
-                            pix.data_ptr(), img.data_ptr())
+                            pix.data_ptr(), img.data_ptr(), tr.data_ptr())
         pin = None
         if pixels is not None:
             px = torch.as_tensor(pixels)
@@ -101,7 +101,9 @@ class DeviceRaySampler:
                                                    self.seed, 0, _lib.ptr(self._counter), _lib.ptr(pin), C.byref(out),
                                                    _lib.stream_ptr(dev)), "sample_rays")
         rays = {"rays_o": rays_o, "rays_v": rays_v, "edge": edge}
-        sample = {"rays": rays, "rays_ndc_uv": uv, "rays_norm_XYZ_cam": pc, "depth_scale": ds, "pixels": pix, "img_idx": img}
+        # "t_rand" is not in the reference's dict: render()'s per-ray jitter (udf_renderer_blending.py:719 draws torch.rand([N,1]) - 0.5 on the
+        # host generator), from the same device draw - pass it as render(..., t_rand=sample["t_rand"]) and the step has no host draw at all
+        sample = {"rays": rays, "rays_ndc_uv": uv, "rays_norm_XYZ_cam": pc, "depth_scale": ds, "pixels": pix, "img_idx": img, "t_rand": tr}
         if img_idx is not None:
             sample["pose"] = self.pose_all[int(img_idx)]
             sample["intrinsics"] = self.intrinsics_all[int(img_idx)]

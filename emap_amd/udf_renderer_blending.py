@@ -303,10 +303,11 @@ class UDFRendererBlending:
         cg.d_variance = flat.data_ptr() + es * lay.offsets[id(extra[0])]
         cg.d_beta = flat.data_ptr() + es * lay.offsets[id(extra[1])]
         cg.d_gamma = flat.data_ptr() + es * lay.offsets[id(extra[2])]
-        if stages & 1:
-            flat[lay.offsets[id(extra[0])]:].zero_()   # second_variance / zeta / unused scalar slots (tiny)
         cg.grad_scale = float(grad_scale)
         cg.accumulate = 0
+        # second_variance / zeta / unused scalar slots (tiny): cleared by the compositing adjoint's reduce kernel, not by a launch of their own
+        o0 = lay.offsets[id(extra[0])]
+        cg.zero_tail, cg.n_zero_tail = flat.data_ptr() + es * o0, lay.numel - o0
         pg, keep = lay.tables(flat)
         pg.grad_scale = float(grad_scale)
         p = call["p"]

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EMAP_ABI_VERSION 7
+#define EMAP_ABI_VERSION 8
 
 /* error codes */
 #define EMAP_OK 0
@@ -226,6 +226,8 @@ typedef struct EmapCompositeGrads {
     float* d_gamma;                              /* out (1) or NULL: dL/d BetaNetwork.gamma      */
     float grad_scale;
     int32_t accumulate;
+    float* zero_tail;                            /* ABI v8, optional: n_zero_tail floats that the launch clears when accumulate == 0 - the gradient */
+    int64_t n_zero_tail;                         /* slots of scalar parameters the path does not reach, so that a caller's flat gradient needs no memset */
 } EmapCompositeGrads;
 
 typedef struct EmapParamGrads {
@@ -307,6 +309,8 @@ typedef struct EmapRayBatch {
     float* p_cam;        /* (N,3)  rays_norm_XYZ_cam */
     int64_t* pixels;     /* (N,2)  x,y */
     int32_t* img_idx;    /* (1)    the image the batch came from */
+    float* t_rand;       /* (N)    ABI v8: render()'s per-ray jitter U(-0.5, 0.5) (udf_renderer_blending.py:719: torch.rand([N,1]) - 0.5 on the host
+                                   generator there), from the same Philox draw as the ray's pixel */
 } EmapRayBatch;
 
 int emap_sample_rays(const EmapRayDataset* ds, int img_idx, int batch, int importance, uint64_t seed, uint64_t offset,

@@ -217,6 +217,84 @@ def test_composite_bwd_vs_mirror(case, car, fs, bg):
         assert abs(float(got) - float(ref)) <= 1e-4 * abs(float(ref)) + 1e-12, nm
 
 
+@pytest.mark.parametrize("S", [1, 2, 63, 64, 65, 127, 129, 200, 256])
+@pytest.mark.parametrize("car,fs", [(None, 0.9), (0.4, 0.0)])
+def test_composite_kernels_at_every_chunking(S, car, fs):
+    """The register-resident compositing kernels (round 5: lane = 1, 2 or 4 consecutive samples, ragged last lanes) at sample counts on
+    both sides of every chunk boundary, synthetic rays: forward weights / edge / depth against the mirror's fp64 forward recomputation,
+    adjoint against oracle/vjp_mirror.composite_bwd - the tolerances of the golden-input tests (1e-4 of each tensor's max)."""
+    gen = torch.Generator().manual_seed(100 + S)
+    N = 37
+    ro = torch.randn(N, 3, generator=gen) * 0.3
+    rd = torch.nn.functional.normalize(torch.randn(N, 3, generator=gen), dim=-1)
+    z = torch.sort(torch.rand(N, S, generator=gen) * 2.0 + 0.5, dim=-1).values
+    udf = torch.rand(N, S, generator=gen) * 0.2 + 1e-3
+    grads = torch.nn.functional.normalize(torch.randn(N, S, 3, generator=gen), dim=-1) * (0.8 + 0.4 * torch.rand(N, S, 1, generator=gen))
+    ds = torch.rand(N, generator=gen) * 0.5 + 0.5
+    sd = torch.tensor([0.03])
+    d_edge, d_depth = torch.randn(N, generator=gen) / N, torch.randn(N, generator=gen) * 0.1 / N
+    net, _, _ = mk("d4w128L10")
+    r = mk_renderer(net, 64, 64, 4)
+    p = r._params(N, car, fs, None)
+    L = _lib.lib()
+    dv = [v.to(DEV).contiguous() for v in (ro, rd, z, udf, grads, ds, sd)]
+    bufs = {k: torch.empty(N, S, device=DEV) for k in ("weights", "alpha")}
+    bufs.update(edge=torch.empty(N, 1, device=DEV), depth=torch.empty(N, 1, device=DEV), scalars=torch.zeros(16, device=DEV))
+    co = _lib.CompositeOut()
+    for k, v in bufs.items():
+        setattr(co, k, v.data_ptr())
+    part8 = torch.empty(N, 8, device=DEV)
+    _lib.check(L.emap_composite_fwd_p(*[_lib.ptr(v) for v in dv[:6]], N, S, _lib.ptr(dv[6]), C.byref(p), C.byref(co), _lib.ptr(part8), None,
+                                      _lib.stream_ptr()), "composite")
+    cg = _lib.CompositeGrads()
+    ten = [d_edge.to(DEV), d_depth.to(DEV), torch.tensor([0.1], device=DEV), torch.tensor([0.05], device=DEV)]
+    cg.d_edge, cg.d_depth, cg.d_gradient_error, cg.d_gradient_error_near_surface = [v.data_ptr() for v in ten]
+    cg.scalars = bufs["scalars"].data_ptr()
+    outs = torch.zeros(3, device=DEV)
+    cg.d_variance, cg.d_beta, cg.d_gamma = outs.data_ptr(), outs.data_ptr() + 4, outs.data_ptr() + 8
+    cg.grad_scale, cg.accumulate = 1.0, 0
+    o_du, o_dg, part4 = torch.empty(N, S, device=DEV), torch.empty(N, S, 3, device=DEV), torch.empty(N, 4, device=DEV)
+    _lib.check(L.emap_composite_bwd(*[_lib.ptr(v) for v in dv[:6]], N, S, _lib.ptr(dv[6]), C.byref(p), C.byref(cg), _lib.ptr(o_du), _lib.ptr(o_dg),
+                                    _lib.ptr(part4), _lib.stream_ptr()), "composite_bwd")
+    torch.cuda.synchronize()
+    dt = torch.float64
+    var, bp, gp = torch.tensor([0.3], dtype=dt), torch.tensor([0.5], dtype=dt), torch.tensor([0.3], dtype=dt)
+    inv_s, beta, gamma = O.inv_s_from_variance(var), O.beta_from_param(bp), O.gamma_from_param(gp)
+    z64, u64, g64, rd64 = z.to(dt), udf.to(dt), grads.to(dt), rd.to(dt)
+    # forward, the mirror's recomputation (oracle/vjp_mirror.py:composite_bwd, "forward recompute")
+    one = torch.ones(N, 1, dtype=dt)
+    dists = torch.cat([z64[:, 1:] - z64[:, :-1], torch.full((N, 1), float(sd), dtype=dt)], -1)
+    tc = (rd64[:, None, :] * g64).sum(-1)
+    E = torch.exp(-beta * u64)
+    occ = 1.0 - torch.exp(-torch.relu(beta * E / (1 + E) ** 2) * gamma * dists)
+    vm = torch.cat([(tc[:, 1:] < 0.01).to(dt), one], -1)
+    a_ = (1.0 - occ + fs * vm).clip(0, 1) + 1e-7
+    vp = torch.cumprod(torch.cat([one, a_], -1), -1)[:, :-1].clip(0, 1)
+    ap = O.sdf2alpha(u64.reshape(-1, 1), -tc.abs().reshape(-1, 1), dists.reshape(-1, 1), inv_s, car).reshape(N, S)
+    am = O.sdf2alpha(-u64.reshape(-1, 1), -tc.abs().reshape(-1, 1), dists.reshape(-1, 1), inv_s, car).reshape(N, S)
+    alpha = ap * vp + am * (1 - vp)
+    w = alpha * torch.cumprod(torch.cat([one, 1.0 - alpha + 1e-7], -1), -1)[:, :-1]
+    assert rel(bufs["alpha"], alpha) <= 1e-4
+    assert rel(bufs["weights"], w) <= 1e-4
+    assert rel(bufs["edge"].reshape(-1), w.sum(-1)) <= 1e-4
+    assert rel(bufs["depth"].reshape(-1), ((z64 + dists * 0.5) * w).sum(-1) * ds.to(dt)) <= 1e-4
+    s = bufs["scalars"].cpu().double()
+    rU, rG, ris, rbt, rgm = M.composite_bwd(ro.to(dt), rd64, z64, float(sd), u64, g64, inv_s, beta, gamma, car, fs, r.near_surface, None,
+                                            d_edge.to(dt).view(N, 1), d_depth.to(dt).view(N, 1), ds.to(dt), 0.1 / (s[4] + 1e-5), 0.05 / (s[6] + 1e-5))
+    assert rel(o_du, rU) <= 1e-4
+    assert rel(o_dg, rG) <= 1e-4
+    o = outs.cpu().double()
+    # the three scalar gradients are signed sums over all N S samples: on synthetic rays they cancel, so the bound is 1e-4 of the value plus a
+    # few times what evaluating the SAME formulas in fp32 instead of fp64 moves the sum (the mirror run on fp32 inputs)
+    f32 = torch.float32
+    q32 = M.composite_bwd(ro.to(f32), rd.to(f32), z.to(f32), float(sd), udf.to(f32), grads.to(f32), inv_s.to(f32), beta.to(f32), gamma.to(f32), car, fs,
+                          r.near_surface, None, d_edge.to(f32).view(N, 1), d_depth.to(f32).view(N, 1), ds.to(f32), float(0.1 / (s[4] + 1e-5)),
+                          float(0.05 / (s[6] + 1e-5)))[2:]
+    for got, ref, r32, k, nm in ((o[0], ris, q32[0], 10 * inv_s, "variance"), (o[1], rbt, q32[1], 10 * beta, "beta"), (o[2], rgm, q32[2], 10 * gamma, "gamma")):
+        ref, noise = float(ref * k), abs(float(r32.double() * k) - float(ref * k))
+        assert abs(float(got) - ref) <= 1e-4 * abs(ref) + 8 * noise + 1e-9, (nm, float(got), ref, noise)
+
+
 def _render_bwd_on_reference_samples(g, prec):
     name = str(g["netname"])
     net, state, cfg = mk(name, prec)
@@ -236,10 +314,16 @@ def _render_bwd_on_reference_samples(g, prec):
     true_edge = t(g["true_edge"]).to(DEV)
     loss = ((edge - true_edge) ** 2).mean() * ew + fwd["scalars"][1] * igr_ns + fwd["scalars"][0] * igr
     d_edge = 2.0 * (edge - true_edge) / N * ew
-    flat = r.backward_into(call, v, d_edge, None, torch.tensor([igr], device=DEV), torch.tensor([igr_ns], device=DEV))
+    lay = r._layout()
+    # the flat gradient arrives full of NaN: every slot is WRITTEN by the backward - the slots of scalar parameters the path does not reach
+    # (second variance, zeta ...) are cleared by the compositing adjoint's reduce kernel (EmapCompositeGrads.zero_tail, ABI v8), not by a memset
+    flat = torch.full((lay.numel,), float("nan"), device=DEV)
+    flat = r.backward_into(call, v, d_edge, None, torch.tensor([igr], device=DEV), torch.tensor([igr_ns], device=DEV), flat=flat)
     torch.cuda.synchronize()
     r.check_errors()
-    lay = r._layout()
+    assert bool(torch.isfinite(flat).all())
+    o_tail = lay.offsets[id(lay.extra[2])] + lay.extra[2].numel()
+    assert o_tail == lay.numel or float(flat[o_tail:].abs().max()) == 0.0
     got = {k: flat[lay.offsets[id(p)]:lay.offsets[id(p)] + p.numel()].view(p.shape).cpu() for k, p in net.named_parameters()}
     extra = {"variance": flat[lay.offsets[id(lay.extra[0])]].cpu(), "beta": flat[lay.offsets[id(lay.extra[1])]].cpu(),
              "gamma": flat[lay.offsets[id(lay.extra[2])]].cpu()}

@@ -217,3 +217,32 @@ def test_step_counter_image_permutation_and_determinism():
     for _ in range(2):
         s5.gen_random_rays_patches_at(None, 64)
     assert torch.equal(s5.gen_random_rays_patches_at(None, 64)["pixels"], p2)  # replayed step 2 == eager step 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch", [37, 512, 1024, 1500, 4096])
+def test_jitter_output_and_counter_for_both_launch_shapes(batch):
+    """ABI v8: `t_rand` (render()'s per-ray jitter, udf_renderer_blending.py:719) comes with the rays - U(-0.5, 0.5) from the ray's own
+    Philox draw; batches of up to 1024 rays run as ONE workgroup that increments the step counter itself, larger ones keep the second launch:
+    the counter advances by exactly one either way and the draw of a step does not depend on which shape ran it."""
+    meta, edges, K, P = _scene(n_images=3, H=40, W=50)
+    s = emap_amd.DeviceRaySampler.from_meta(meta, edges.numpy(), device="cuda:0", seed=21)
+    a = [s.gen_random_rays_patches_at(None, batch, importance_sample=True) for _ in range(3)]
+    torch.cuda.synchronize()
+    assert int(s._counter.item()) == 3
+    t0, t1 = a[0]["t_rand"], a[1]["t_rand"]
+    assert t0.shape == (batch, 1) and float(t0.min()) >= -0.5 and float(t0.max()) < 0.5
+    assert not torch.equal(t0, t1)
+    if batch >= 512:
+        allt = torch.cat([x["t_rand"] for x in a]).double().cpu()
+        assert abs(float(allt.mean())) < 4 * (1 / 12) ** 0.5 / (3 * batch) ** 0.5        # 4 sigma of the mean of U(-0.5, 0.5)
+        assert abs(float(allt.var()) - 1 / 12) < 0.01
+    # the first min(batch, 37) rays of a step are the same whatever the batch size (index = ray): one-workgroup and multi-workgroup launches agree
+    s2 = emap_amd.DeviceRaySampler.from_meta(meta, edges.numpy(), device="cuda:0", seed=21)
+    b = s2.gen_random_rays_patches_at(None, 2048 if batch <= 1024 else 1024)
+    n = min(batch, 1024)
+    assert torch.equal(b["t_rand"][:n], t0[:n])
+    # given pixels: the jitter is still drawn
+    pix = torch.stack([torch.arange(batch) % 50, torch.arange(batch) % 40], -1)
+    c = s.gen_random_rays_patches_at(1, batch, pixels=pix)
+    assert float(c["t_rand"].abs().max()) > 0 and torch.equal(c["pixels"].cpu(), pix)
