@@ -311,6 +311,7 @@ __global__ __launch_bounds__(64) void sampler_step_kernel(const StepArgs a) {
     if constexpr (COARSE) {
         // sample_dist = ((far - near) / n_samples).mean() (:704): every wave forms the same fp64 sum in the same order
         double sum = 0.0;
+#pragma unroll 8      // loads of 8 iterations in flight (the adds stay in order): at 4096 rays this loop was 15 of the step's 25 us
         for (int r = lane; r < a.N; r += 64) sum += (double)FDIV(FSUB(a.far[r], a.near[r]), (float)n);
         sd = (float)(wave_sum_d(sum) / (double)a.N);
         if (ray == 0 && lane == 0) *a.sample_dist = sd;
