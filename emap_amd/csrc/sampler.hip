@@ -91,6 +91,38 @@ __device__ __forceinline__ void wave_scan(const float* in, float* out, int n, in
     }
 }
 
+// lane l <- lane l+1 (wave_shl:1); lane 63 keeps `ident`
+__device__ __forceinline__ float dpp_next_f(float ident, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, ident), __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+}
+// exclusive prefix product over the ray, registers in / out: lane l holds samples [l C, (l+1) C) - wave_scan<true>'s arithmetic on the same chunks
+template <int C>
+__device__ __forceinline__ void ray_prefix_prod(const float (&in)[C], const bool (&ok)[C], float (&out)[C]) {
+    double loc = 1.0;
+#pragma unroll
+    for (int i = 0; i < C; ++i) if (ok[i]) loc *= (double)in[i];
+    const double inc = wave_scan_incl_d<true>(loc);
+    double run = dpp_d<0x138, 0xf>(1.0, inc);
+#pragma unroll
+    for (int i = 0; i < C; ++i) { out[i] = (float)run; if (ok[i]) run *= (double)in[i]; }
+}
+
+// lane l <- lane l-1 (wave_shr:1); lane 0 keeps `ident`
+__device__ __forceinline__ float dpp_prev_f(float ident, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, ident), __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+// inclusive prefix sum over the ray, registers in / out: wave_scan<false>'s arithmetic on chunks of C
+template <int C>
+__device__ __forceinline__ void ray_prefix_sum(const float (&in)[C], const bool (&ok)[C], float (&out)[C]) {
+    double loc = 0.0;
+#pragma unroll
+    for (int i = 0; i < C; ++i) if (ok[i]) loc += (double)in[i];
+    const double inc = wave_scan_incl_d<false>(loc);
+    double run = dpp_d<0x138, 0xf>(0.0, inc);
+#pragma unroll
+    for (int i = 0; i < C; ++i) { if (ok[i]) run += (double)in[i]; out[i] = (float)run; }
+}
+
 // torch.linspace(start, end, steps)[i] for fp32 (ATen RangeFactories: step = (end-start)/(steps-1),
 // first half counted up from start, second half counted down from end).
 __device__ __forceinline__ float linspace_at(float start, float end, int steps, int i) {
@@ -133,20 +165,9 @@ __device__ __forceinline__ float udf2logistic1(float udf, float inv_s) {
 // ---------------------------------------------------------------------------------------------
 // sample_pdf on LDS data (bins[n], w[n-1] raw weights; scratch pdf[n], cdf[n])
 // ---------------------------------------------------------------------------------------------
-// u_in (optional, m values of this ray): the caller's uniform draws - sample_pdf(det=False), :84-85 - instead of the deterministic grid
-__device__ __forceinline__ void sample_pdf_wave(const float* bins, const float* w, float* pdf, float* cdf, int n, int m,
-                                                int lane, float* samples_out, int64_t* inds_out, int32_t* err, const float* u_in = nullptr) {
-    const int nw = n - 1;
-    double part = 0.0;
-    for (int e = lane; e < nw; e += 64) {
-        const float we = FADD(w[e], 1e-5f);
-        pdf[e] = we;
-        part += (double)we;
-    }
-    const float total = (float)wave_sum_d(part);
-    for (int e = lane; e < nw; e += 64) pdf[e] = FDIV(pdf[e], total);
-    wave_scan<false>(pdf, cdf + 1, nw, lane);
-    if (lane == 0) cdf[0] = 0.0f;
+// the inverse-CDF look-up of sample_pdf (:86-109) on LDS arrays bins[n], cdf[n] (cdf[0] = 0): m samples, lane k < m each
+__device__ __forceinline__ void sample_pdf_search(const float* bins, const float* cdf, int n, int m, int lane, float* samples_out,
+                                                  int64_t* inds_out, int32_t* err, const float* u_in) {
     const float u0 = (float)(0.0 + 0.5 / (double)m), u1 = (float)(1.0 - 0.5 / (double)m);
     bool nan = false;
     for (int k = lane; k < m; k += 64) {
@@ -171,6 +192,23 @@ __device__ __forceinline__ void sample_pdf_wave(const float* bins, const float* 
     if (err && __any(nan)) { if (lane == 0) atomicOr(err, EMAP_F_NAN_SAMPLES); }
 }
 
+// u_in (optional, m values of this ray): the caller's uniform draws - sample_pdf(det=False), :84-85 - instead of the deterministic grid
+__device__ __forceinline__ void sample_pdf_wave(const float* bins, const float* w, float* pdf, float* cdf, int n, int m,
+                                                int lane, float* samples_out, int64_t* inds_out, int32_t* err, const float* u_in = nullptr) {
+    const int nw = n - 1;
+    double part = 0.0;
+    for (int e = lane; e < nw; e += 64) {
+        const float we = FADD(w[e], 1e-5f);
+        pdf[e] = we;
+        part += (double)we;
+    }
+    const float total = (float)wave_sum_d(part);
+    for (int e = lane; e < nw; e += 64) pdf[e] = FDIV(pdf[e], total);
+    wave_scan<false>(pdf, cdf + 1, nw, lane);
+    if (lane == 0) cdf[0] = 0.0f;
+    sample_pdf_search(bins, cdf, n, m, lane, samples_out, inds_out, err, u_in);
+}
+
 __global__ __launch_bounds__(64) void sample_pdf_kernel(const float* bins, const float* weights, int N, int n, int m,
                                                         float* samples, int64_t* inds, int32_t* err, const float* u) {
     __shared__ float s_bins[MAXS], s_w[MAXS], s_pdf[MAXS], s_cdf[MAXS + 1];
@@ -185,53 +223,92 @@ __global__ __launch_bounds__(64) void sample_pdf_kernel(const float* bins, const
 // ---------------------------------------------------------------------------------------------
 // up_sample_unbias (udf_renderer_blending.py:228-353) -> z_new (N,m)
 // ---------------------------------------------------------------------------------------------
-struct UpsampleScratch { float rad[MAXS], tc[MAXS], a[MAXS], b[MAXS], c[MAXS], d[MAXS + 1]; };
+struct UpsampleScratch { float a[MAXS], d[MAXS + 1]; };      // a: staging of the merge, d: cdf of sample_pdf
 
-// the whole of up_sample_unbias on the LDS arrays s_z, s_u (n entries, filled and synchronised by the caller); the m new
-// samples go to samples_out (global or LDS), their searchsorted indices to inds_out (may be null)
+// the whole of up_sample_unbias on the LDS lists s_z, s_u (n entries, filled and synchronised by the caller); the m new samples go to
+// samples_out (global or LDS), their searchsorted indices to inds_out (may be null).
+// Round 5: between the sorted lists (which merge and searchsorted need in LDS) and the cdf (ditto) everything lives in REGISTERS - lane l
+// holds the C consecutive samples [l C, (l+1) C) and the intervals that start at them, neighbours come over the DPP network, the three scans
+// run on the same chunks as the LDS scans did.  Same expressions, same results (the fp64 sum of the weights is exact in any order: floats
+// between 1e-5 and ~1); rounds 1-4 made eight passes over six LDS arrays with a barrier after each.
+template <int C>
+__device__ __forceinline__ void upsample_body_c(float ox, float oy, float oz, float dx, float dy, float dz, float sd, const float* s_z,
+                                                const float* s_u, UpsampleScratch& w, int n, int m, float inv_s, float beta, float gamma,
+                                                int lane, float* samples_out, int64_t* inds_out, int32_t* err) {
+    float z[C + 1], u[C + 1], rad[C + 1], tc[C];
+    bool ok[C], oki[C];            // sample e exists / interval [e, e+1] exists
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+        const int e = lane * C + i;
+        ok[i] = e < n; oki[i] = e < n - 1;
+        const int ec = ok[i] ? e : n - 1;
+        z[i] = s_z[ec]; u[i] = s_u[ec];
+    }
+    z[C] = dpp_next_f(0.f, z[0]);          // sample e+1 of a lane's last sample is the next lane's first
+    u[C] = dpp_next_f(0.f, u[0]);
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+        const float px = FADD(ox, FMUL(dx, z[i])), py = FADD(oy, FMUL(dy, z[i])), pz = FADD(oz, FMUL(dz, z[i]));
+        rad[i] = sqrtf(FADD(FADD(FMUL(px, px), FMUL(py, py)), FMUL(pz, pz)));  // :249
+    }
+    rad[C] = dpp_next_f(0.f, rad[0]);
+    // true_cos over intervals (:279)
+#pragma unroll
+    for (int i = 0; i < C; ++i) tc[i] = FDIV(FSUB(u[i + 1], u[i]), FADD(FSUB(z[i + 1], z[i]), 1e-5f));
+    const float tc_left = dpp_prev_f(0.f, tc[C - 1]);      // true_cos of the interval that ENDS at this lane's first sample
+    float av[C], sb[C];
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+        const int e = lane * C + i;
+        const float tcp = i ? tc[i ? i - 1 : 0] : tc_left;
+        const float dists_raw = oki[i] ? FSUB(z[i + 1], z[i]) : sd;                       // :254-263
+        const float vis_mask = (e == 0) ? 1.0f : ((tcp < 0.05f) ? 1.0f : 0.0f);           // :293-300
+        const float raw_occ = udf2logistic1(u[i], beta);                                  // :303
+        const float alpha_occ = FSUB(1.0f, expf(FMUL(FMUL(-relu_(raw_occ), gamma), dists_raw)));  // :305
+        av[i] = FADD(clipf(FADD(FSUB(1.0f, alpha_occ), vis_mask), 0.0f, 1.0f), 1e-7f);    // :312
+    }
+    ray_prefix_prod<C>(av, ok, sb);        // vis_prob (:308-319)
+    float alpha[C];
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+        const int e = lane * C + i;
+        const float tcp = i ? tc[i ? i - 1 : 0] : tc_left;
+        const float cv = -fabsf(tc[i]);
+        const float pcv = (e == 0) ? 0.0f : -fabsf(tcp);
+        const bool inside = (rad[i] < 1.0f) | (rad[i + 1] < 1.0f);                        // :250
+        float cos_val = clipf(fminf(pcv, cv), -1e3f, 0.0f);                               // :284-290
+        cos_val = inside ? cos_val : FMUL(cos_val, 0.0f);
+        const float mid_udf = FMUL(FADD(u[i], u[i + 1]), 0.5f);
+        const float dists = FSUB(z[i + 1], z[i]);
+        const float ap = sdf2alpha(mid_udf, cos_val, dists, inv_s, false, 0.f);           // :327-330
+        const float am = sdf2alpha(-mid_udf, cos_val, dists, inv_s, false, 0.f);
+        alpha[i] = FADD(FMUL(ap, sb[i]), FMUL(am, FSUB(1.0f, sb[i])));                    // :331
+        av[i] = FADD(FSUB(1.0f, alpha[i]), 1e-7f);
+    }
+    ray_prefix_prod<C>(av, oki, sb);       // transmittance (:334-343)
+    // sample_pdf (:69-109) on the weights alpha * T of the n - 1 intervals
+    double part = 0.0;
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+        av[i] = FADD(FMUL(alpha[i], sb[i]), 1e-5f);
+        if (oki[i]) part += (double)av[i];
+    }
+    const float total = (float)wave_sum_d(part);
+#pragma unroll
+    for (int i = 0; i < C; ++i) av[i] = FDIV(av[i], total);
+    ray_prefix_sum<C>(av, oki, sb);
+#pragma unroll
+    for (int i = 0; i < C; ++i) if (oki[i]) w.d[lane * C + i + 1] = sb[i];
+    if (lane == 0) w.d[0] = 0.0f;
+    sample_pdf_search(s_z, w.d, n, m, lane, samples_out, inds_out, err, nullptr);
+}
+
 __device__ __forceinline__ void upsample_body(float ox, float oy, float oz, float dx, float dy, float dz, float sd, const float* s_z,
                                               const float* s_u, UpsampleScratch& w, int n, int m, float inv_s, float beta, float gamma,
                                               int lane, float* samples_out, int64_t* inds_out, int32_t* err) {
-    for (int e = lane; e < n; e += 64) {
-        const float zz = s_z[e];
-        const float px = FADD(ox, FMUL(dx, zz)), py = FADD(oy, FMUL(dy, zz)), pz = FADD(oz, FMUL(dz, zz));
-        w.rad[e] = sqrtf(FADD(FADD(FMUL(px, px), FMUL(py, py)), FMUL(pz, pz)));  // :249
-    }
-    // true_cos over intervals (:279) and vis_prob input over samples (:293-313)
-    for (int e = lane; e < n - 1; e += 64)
-        w.tc[e] = FDIV(FSUB(s_u[e + 1], s_u[e]), FADD(FSUB(s_z[e + 1], s_z[e]), 1e-5f));
-    __syncthreads();
-    for (int e = lane; e < n; e += 64) {
-        const float dists_raw = (e < n - 1) ? FSUB(s_z[e + 1], s_z[e]) : sd;           // :254-263
-        const float vis_mask = (e == 0) ? 1.0f : ((w.tc[e - 1] < 0.05f) ? 1.0f : 0.0f);  // :293-300
-        const float raw_occ = udf2logistic1(s_u[e], beta);                               // :303
-        const float alpha_occ = FSUB(1.0f, expf(FMUL(FMUL(-relu_(raw_occ), gamma), dists_raw)));  // :305
-        w.a[e] = FADD(clipf(FADD(FSUB(1.0f, alpha_occ), vis_mask), 0.0f, 1.0f), 1e-7f);  // :312
-    }
-    __syncthreads();
-    wave_scan<true>(w.a, w.b, n, lane);  // vis_prob (:308-319)
-    __syncthreads();
-    for (int e = lane; e < n - 1; e += 64) {
-        const float cv = -fabsf(w.tc[e]);
-        const float pcv = (e == 0) ? 0.0f : -fabsf(w.tc[e - 1]);
-        const bool inside = (w.rad[e] < 1.0f) | (w.rad[e + 1] < 1.0f);                   // :250
-        float cos_val = clipf(fminf(pcv, cv), -1e3f, 0.0f);                              // :284-290
-        cos_val = inside ? cos_val : FMUL(cos_val, 0.0f);
-        const float mid_udf = FMUL(FADD(s_u[e], s_u[e + 1]), 0.5f);
-        const float dists = FSUB(s_z[e + 1], s_z[e]);
-        const float ap = sdf2alpha(mid_udf, cos_val, dists, inv_s, false, 0.f);          // :327-330
-        const float am = sdf2alpha(-mid_udf, cos_val, dists, inv_s, false, 0.f);
-        const float sp = w.b[e];
-        const float alpha = FADD(FMUL(ap, sp), FMUL(am, FSUB(1.0f, sp)));               // :331
-        w.c[e] = alpha;
-        w.a[e] = FADD(FSUB(1.0f, alpha), 1e-7f);
-    }
-    __syncthreads();
-    wave_scan<true>(w.a, w.b, n - 1, lane);  // transmittance (:334-343)
-    __syncthreads();
-    for (int e = lane; e < n - 1; e += 64) w.c[e] = FMUL(w.c[e], w.b[e]);  // weights
-    __syncthreads();
-    sample_pdf_wave(s_z, w.c, w.a, w.d, n, m, lane, samples_out, inds_out, err);
+    if (n <= 64) upsample_body_c<1>(ox, oy, oz, dx, dy, dz, sd, s_z, s_u, w, n, m, inv_s, beta, gamma, lane, samples_out, inds_out, err);
+    else if (n <= 128) upsample_body_c<2>(ox, oy, oz, dx, dy, dz, sd, s_z, s_u, w, n, m, inv_s, beta, gamma, lane, samples_out, inds_out, err);
+    else upsample_body_c<4>(ox, oy, oz, dx, dy, dz, sd, s_z, s_u, w, n, m, inv_s, beta, gamma, lane, samples_out, inds_out, err);
 }
 
 __global__ __launch_bounds__(64) void upsample_kernel(const float* rays_o, const float* rays_d, const float* z,
@@ -410,22 +487,6 @@ struct CompositeArgs {
 
 __device__ void composite_reduce_body(const float* partials, int N, float* scalars, int32_t* err, const CompositeArgs& a, int tid, int nthreads,
                                       double (*red)[5]);
-
-// lane l <- lane l+1 (wave_shl:1); lane 63 keeps `ident`
-__device__ __forceinline__ float dpp_next_f(float ident, float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, ident), __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
-}
-// exclusive prefix product over the ray, registers in / out: lane l holds samples [l C, (l+1) C) - wave_scan<true>'s arithmetic on the same chunks
-template <int C>
-__device__ __forceinline__ void ray_prefix_prod(const float (&in)[C], const bool (&ok)[C], float (&out)[C]) {
-    double loc = 1.0;
-#pragma unroll
-    for (int i = 0; i < C; ++i) if (ok[i]) loc *= (double)in[i];
-    const double inc = wave_scan_incl_d<true>(loc);
-    double run = dpp_d<0x138, 0xf>(1.0, inc);
-#pragma unroll
-    for (int i = 0; i < C; ++i) { out[i] = (float)run; if (ok[i]) run *= (double)in[i]; }
-}
 
 // Round 5: the ray lives in registers (lane l = samples [l C, (l+1) C), C = 1, 2 or 4), one burst of loads, neighbours over DPP, no LDS and
 // no barriers - see composite_bwd_kernel.  Same expressions and the same scan chunks as the LDS version of rounds 1-4.
