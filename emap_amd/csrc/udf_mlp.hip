@@ -60,6 +60,15 @@ __global__ __launch_bounds__(256) void rowscale_kernel(const PackArgs a) {
     }
 }
 
+// W_l[o][col] * rowscale * mult, or 0 outside the matrix - the two loads are UNCONDITIONAL on clamped indices (a branch per element kept
+// the compiler from batching the 8 / 32 independent gathers of a thread: each waited for its own round trip)
+__device__ __forceinline__ float packed_weight(const PackArgs& a, const float* rs, int l, int H, int o, int col, int out_dim, int n_in, float mult) {
+    const bool ok = (o < out_dim) & (col >= 0) & (col < n_in);
+    const int oc = min(max(o, 0), out_dim - 1), cc = min(max(col, 0), n_in - 1);
+    const float w = rs[l * H + oc] * a.v[l][(size_t)oc * n_in + cc] * mult;
+    return ok ? w : 0.f;
+}
+
 __device__ __forceinline__ void pack_body(const PackArgs& a, unsigned block) {
     const long long gid = (long long)block * 256 + threadIdx.x;  // one thread per (fragment, lane)
     const long long F = gid >> 6;
@@ -104,8 +113,7 @@ __device__ __forceinline__ void pack_body(const PackArgs& a, unsigned block) {
             const int f = 16 * (2 * sh + (e >> 2)) + 4 * g + (e & 3);
             if (f < Ld.in_prev) col = f;
         }
-        float w = 0.f;
-        if (o < Ld.out_dim && col >= 0 && col < n_in) w = rs[l * H + o] * a.v[l][(size_t)o * n_in + col] * mult;
+        const float w = packed_weight(a, rs, l, H, o, col, Ld.out_dim, n_in, mult);
         const __bf16 hi = (__bf16)w;
         outv[e] = (part == 0) ? hi : (__bf16)(w - (float)hi);
         const _Float16 hh = (_Float16)w;
@@ -175,8 +183,7 @@ __device__ __forceinline__ void pack_t_body(const PackArgs& a, unsigned block) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int o = 16 * (2 * s + (e >> 2)) + 4 * g + (e & 3);
-        float w = 0.f;
-        if (o < Ld.out_dim && col >= 0 && col < n_in) w = rs[l * H + o] * a.v[l][(size_t)o * n_in + col] * mult;
+        const float w = packed_weight(a, rs, l, H, o, col, Ld.out_dim, n_in, mult);
         const __bf16 hi = (__bf16)w;
         outv[e] = (part == 0) ? hi : (__bf16)(w - (float)hi);
         const _Float16 hh = (_Float16)w;
@@ -300,7 +307,7 @@ __device__ __forceinline__ void pack32_body(const PackArgs& a, unsigned block) {
             const int f = 32 * (S - Ld.pe_ks) + (e & 3) + 8 * (2 * u + (e >> 2)) + 4 * hh;
             if (f < Ld.in_prev) col = f;
         }
-        return (o < Ld.out_dim && col >= 0 && col < n_in) ? rs[l * H + o] * a.v[l][(size_t)o * n_in + col] * mult : 0.f;
+        return packed_weight(a, rs, l, H, o, col, Ld.out_dim, n_in, mult);
     };
     if (r32_mixed(a.L)) {      // MX-fp6 forward sweep: one 8 KiB block per (row tile, K64-step) - every layer has an even number of K32-steps
         const int f = idx & 7; idx >>= 3;
@@ -363,7 +370,7 @@ __device__ __forceinline__ void pack32_t_body(const PackArgs& a, unsigned block)
     };
     auto weight = [&](int col, int S, int u, int e) -> float {
         const int o = 32 * S + (e & 3) + 8 * (2 * u + (e >> 2)) + 4 * hh;
-        return (o < Ld.out_dim && col >= 0 && col < n_in) ? rs[l * H + o] * a.v[l][(size_t)o * n_in + col] * mult : 0.f;
+        return packed_weight(a, rs, l, H, o, col, Ld.out_dim, n_in, mult);
     };
     char* dst = a.packed + a.L.r32_t_frag_off_bytes + F * FRAG_BYTES + lane * 16;
     if (!r32_t_mixed(a.L)) {
@@ -427,9 +434,9 @@ __device__ __forceinline__ void pack_swm_body(const PackArgs& a, unsigned block)
     for (int idx = 0; idx < 32; ++idx) {
         const int gq = idx >> 3, e = idx & 7;
         const int f = 16 * (2 * s + (e >> 2)) + 4 * gq + (e & 3);
-        float w = 0.f;
-        if (!tr) { if (row < Ld.out_dim && f < Ld.in_prev) w = rs[l * H + row] * a.v[l][(size_t)row * n_in + f] * mult; }
-        else { if (f < Ld.out_dim && row < Ld.in_prev) w = rs[l * H + f] * a.v[l][(size_t)f * n_in + row] * mult; }
+        // forward: W[row][f], f < in_prev; transposed: W[f][row], row < in_prev
+        const int wo = tr ? f : row, wc = tr ? row : f;
+        const float w = packed_weight(a, rs, l, H, wo, (wc < Ld.in_prev) ? wc : -1, Ld.out_dim, n_in, mult);
         const _Float16 h16 = (_Float16)w;
         const _Float16 l16 = (_Float16)((w - (float)h16) * 2048.0f);
         vh[idx] = h16; vl[idx] = l16;
@@ -549,12 +556,15 @@ void build_vjp_layout(const NetLayout& L, VjpLayout* V) {
 
 __global__ __launch_bounds__(256) void pack_all_kernel(const PackArgs a, unsigned nb0, unsigned nb1, unsigned nb2) {
     const unsigned b = blockIdx.x;
-    if (b < nb0) pack_body(a, b);
-    else if (b < nb0 + nb1) pack_t_body(a, b - nb0);
-    else if (b < 2 * nb0 + nb1) pack32_body(a, b - nb0 - nb1);
-    else if (b < 2 * (nb0 + nb1)) pack32_t_body(a, b - 2 * nb0 - nb1);
-    else if (b < 2 * (nb0 + nb1) + nb2) pack_wlast_body(a, b - 2 * (nb0 + nb1));
-    else pack_swm_body(a, b - 2 * (nb0 + nb1) - nb2);
+#ifndef EMAP_PACK_SECTIONS
+#define EMAP_PACK_SECTIONS 63      // timing builds: bit per section (scripts/r5/pack_time.py)
+#endif
+    if (b < nb0) { if (EMAP_PACK_SECTIONS & 1) pack_body(a, b); }
+    else if (b < nb0 + nb1) { if (EMAP_PACK_SECTIONS & 2) pack_t_body(a, b - nb0); }
+    else if (b < 2 * nb0 + nb1) { if (EMAP_PACK_SECTIONS & 4) pack32_body(a, b - nb0 - nb1); }
+    else if (b < 2 * (nb0 + nb1)) { if (EMAP_PACK_SECTIONS & 8) pack32_t_body(a, b - 2 * nb0 - nb1); }
+    else if (b < 2 * (nb0 + nb1) + nb2) { if (EMAP_PACK_SECTIONS & 16) pack_wlast_body(a, b - 2 * (nb0 + nb1)); }
+    else { if (EMAP_PACK_SECTIONS & 32) pack_swm_body(a, b - 2 * (nb0 + nb1) - nb2); }
 }
 
 int launch_pack(const NetLayout& L, const float* const* g, const float* const* v, const float* const* b,
