@@ -414,3 +414,44 @@ def test_masked_selection_reduces_without_materialising():
     assert torch.equal(u[3], x[3]) and torch.equal(u[:, 2], x[:, 2]) and type(u + 1) is torch.Tensor   # ordinary indexing / ops untouched
     full = x.clone().as_subclass(LazyMaskable)[torch.rand(37, 9, generator=g) > 0.5]
     assert isinstance(full, MaskedSelection)
+
+
+def test_ctypes_structs_match_the_header_field_for_field(tmp_path):
+    """Every struct of include/emap_hip.h against its ctypes mirror in emap_amd/_lib.py: a C program compiled from the header prints sizeof
+    and offsetof of every field; same field names, in order, at the same offsets (a field added to one side only - ABI v8 added three -
+    would otherwise show up as a wrong pointer on the GPU box)."""
+    import ctypes as C
+    import re
+    import shutil
+    import subprocess
+    from emap_amd import _lib
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if cc is None:
+        pytest.skip("no C compiler")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "emap_hip.h")).read()
+    pairs = {"EmapNetConfig": _lib.NetConfig, "EmapCompositeOut": _lib.CompositeOut, "EmapRenderParams": _lib.RenderParams,
+             "EmapCompositeGrads": _lib.CompositeGrads, "EmapParamGrads": _lib.ParamGrads, "EmapRayDataset": _lib.RayDataset,
+             "EmapRayBatch": _lib.RayBatch}
+    assert set(re.findall(r"typedef struct (\w+) \{", hdr)) == set(pairs), "a struct of the header has no ctypes mirror (or vice versa)"
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "emap_hip.h"', 'int main(void) {']
+    for cname, cls in pairs.items():
+        lines.append(f'printf("{cname} size %zu\\n", sizeof({cname}));')
+        for f, _ in cls._fields_:
+            lines.append(f'printf("{cname} {f} %zu\\n", offsetof({cname}, {f}));')
+    lines += ["return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run([cc, "-I", os.path.join(root, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
+    got = {tuple(l.split()[:2]): int(l.split()[2]) for l in out if l.strip()}
+    for cname, cls in pairs.items():
+        assert got[(cname, "size")] == C.sizeof(cls), cname
+        for f, _ in cls._fields_:
+            assert got[(cname, f)] == getattr(cls, f).offset, (cname, f)
+        # and no field of the header is missing from the mirror: count the members between the braces
+        body = hdr[hdr.index(f"typedef struct {cname} {{"):hdr.index(f"}} {cname};")]
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        n_members = sum(len(decl.split(",")) for decl in body.split("{", 1)[1].split(";") if decl.strip())
+        assert n_members == len(cls._fields_), (cname, n_members, len(cls._fields_))
