@@ -67,3 +67,36 @@ def test_load_that_overwrites_an_mfma_operand_needs_wait_states(tmp_path):
     assert v == []
     v, _ = run(tmp_path, mfma + bare.replace("v[10:13]", "v[40:43]") + WAIT.format(n=0))   # unrelated destination: fine
     assert v == []
+
+
+def test_hot_kernels_of_the_built_library_do_not_spill_and_the_compositing_adjoint_has_no_atomics():
+    """Structural properties of the ISA that build.sh leaves next to the library (emap_amd/lib/isa/*.s): no kernel of the hot path spills a
+    vector register (metadata .vgpr_spill_count 0 and not one scratch_ instruction in the unit: a spill in one of them once cost 30 %; a few
+    kernels keep a dead 36-byte frame, which is not a spill), and composite_bwd_kernel carries no global atomic - two atomicMax per ray on
+    one cache line cost 10.5 ns EACH, serialised (round 5: 85 of the kernel's 100 us at 4096 rays)."""
+    import glob
+    import re
+    import pytest
+    files = glob.glob(os.path.join(ROOT, "emap_amd", "lib", "isa", "*gfx950*.s"))
+    if not files:
+        pytest.skip("library not built here (emap_amd/csrc/build.sh writes emap_amd/lib/isa)")
+    hot = ("udf_mlp_rev32_kernel", "udf_mlp_fs2_kernel", "udf_mlp_vjp_kernel", "wgrad_kernel", "composite_kernel", "composite_bwd_kernel",
+           "sampler_step_kernel", "adam_kernel", "pack_all_kernel")
+    seen = set()
+    for f in files:
+        text = open(f).read()
+        split_fp16_unit = "udf_mlp_f16x3" in os.path.basename(f)
+        md = text[text.index("amdhsa.kernels:"):] if "amdhsa.kernels:" in text else ""
+        for blk in md.split("  - .agpr_count")[1:]:
+            name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+            key = next((h for h in hot if h in name), None)
+            if key is None or (key.startswith("udf_mlp") and not split_fp16_unit):
+                continue          # MLP kernels: the split-fp16 unit (the default mode and its variants)
+            seen.add(key)
+            assert int(re.search(r"\.vgpr_spill_count:\s+(\d+)", blk).group(1)) == 0, name
+        if split_fp16_unit or "sampler" in os.path.basename(f) or "wgrad" in os.path.basename(f):
+            assert not re.search(r"^\s*scratch_(load|store)", text, flags=re.M), os.path.basename(f)
+        for m in re.finditer(r"^(_ZN4emap20composite_bwd_kernel\w+):[^\n]*\n(.*?)\n\s*s_endpgm", text, flags=re.S | re.M):
+            assert not re.search(r"\b(global|flat|buffer)_atomic", m.group(2)), m.group(1)
+            seen.add("composite_bwd_body")
+    assert seen >= set(hot) | {"composite_bwd_body"}, sorted(set(hot) - seen)
