@@ -53,7 +53,25 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, flo
     if (threadIdx.x == 0) { s_bc[0] = (float)(1.0 - pow(b1d, (double)t)); s_bc[1] = (float)sqrt(1.0 - pow(b2d, (double)t)); }
     __syncthreads();
     const float bc1 = s_bc[0], bc2s = s_bc[1];
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    // the geometry range in float4 words when the four buffers are 16-byte aligned (the flat buffers are): a quarter of the threads and memory
+    // instructions of the element-wise form (11 -> 7 us at 463 k parameters); the rest - the last < 4 geometry elements and the scalar tail with
+    // its mask and per-element step counts - element by element.  Same arithmetic per element either way.
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const bool al = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15) == 0;
+    const long long n4 = al ? (n_geo >> 2) : 0;
+    const float ss_geo = lr_geo / bc1;
+    for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < n4; q += (long long)gridDim.x * 256) {
+        const f4 gi = reinterpret_cast<const f4*>(g)[q];
+        f4 mi = reinterpret_cast<f4*>(m)[q], vi = reinterpret_cast<f4*>(v)[q], pi = reinterpret_cast<f4*>(p)[q];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            mi[k] = mi[k] + (gi[k] - mi[k]) * omb1;
+            vi[k] = b2 * vi[k] + omb2 * gi[k] * gi[k];
+            pi[k] -= ss_geo * mi[k] / (sqrtf(vi[k]) / bc2s + eps);
+        }
+        reinterpret_cast<f4*>(m)[q] = mi; reinterpret_cast<f4*>(v)[q] = vi; reinterpret_cast<f4*>(p)[q] = pi;
+    }
+    for (long long i = 4 * n4 + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         float c1 = bc1, c2s = bc2s;
         if (i >= n_geo && tail_mask) {
             if (tail_mask[i - n_geo] == 0.0f) continue;                  // frozen: no update, no state change
@@ -89,7 +107,8 @@ int launch_adam(float* p, const float* g, float* m, float* v, float* step, int64
         return EMAP_E_INVALID;
     }
     if (n == 0) return EMAP_OK;
-    const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    const int64_t work = n_geo / 4 + (n - (n_geo & ~(int64_t)3));      // float4 words of the geometry range + the remaining elements
+    const int grid = (int)((work + 255) / 256 < 4096 ? (work + 255) / 256 : 4096);
     hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, st, p, g, m, v, step, (long long)n, (long long)n_geo, lr_geo, lr, b1, b2, eps, tail_mask, tail_step);
     hipLaunchKernelGGL(adam_bump_kernel, dim3(1), dim3(1), 0, st, step);
     return check_launch("adam_step");
