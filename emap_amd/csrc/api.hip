@@ -207,6 +207,7 @@ using namespace emap;
 extern "C" {
 
 int emap_abi_version(void) { return EMAP_ABI_VERSION; }
+int emap_set_fused_sampling(int on) { return set_fused_sampling(on); }
 const char* emap_last_error(void) { return g_err; }
 int emap_set_grad_mode(int mode) { return set_grad_mode(mode); }
 
@@ -373,8 +374,15 @@ int emap_render_fwd(const EmapNetConfig* cfg, const void* packed, int prec, cons
         rc = launch_mlp(L, packed, prec, src, (int64_t)N * Sc, ubuf[0], nullptr, st, err_flags);
         if (rc) return rc;
         src.coarse = 0;
+        // everything from here to the final z_vals in ONE launch where the shape allows (16 new samples per ray and step, below 2048 rays):
+        // sampler steps and MLP passes alternate inside the workgroup that owns the rays (udf_mlp_kernel.inc, IS)
+        IsLaunch q;
+        q.rays_o = rays_o; q.rays_d = rays_d; q.near = near; q.far = far; q.t_rand = t_rand; q.sample_dist = sample_dist;
+        q.udf_coarse = ubuf[0]; q.z_final = z_vals; q.N = N; q.Sc = Sc; q.m = m; q.steps = steps;
+        rc = launch_importance(L, packed, prec, q, st, err_flags);
+        if (rc < 0) return rc;
         int cur = 0, n = Sc;
-        for (int i = 0; i < steps; ++i) {
+        for (int i = 0; rc == IS_NOT_FUSED && i < steps; ++i) {
             const bool last = (i + 1 == steps);
             StepArgs a;
             memset(&a, 0, sizeof(a));
@@ -392,12 +400,12 @@ int emap_render_fwd(const EmapNetConfig* cfg, const void* packed, int prec, cons
                 cur ^= 1;
                 n += m;
             }
-            rc = launch_sampler_step(i == 0, last, a, st);
-            if (rc) return rc;
+            int rc2 = launch_sampler_step(i == 0, last, a, st);
+            if (rc2) return rc2;
             if (!last) {
                 src.z = znew[i & 1]; src.n_per_ray = m;
-                rc = launch_mlp(L, packed, prec, src, (int64_t)N * m, udf_new, nullptr, st, err_flags);
-                if (rc) return rc;
+                rc2 = launch_mlp(L, packed, prec, src, (int64_t)N * m, udf_new, nullptr, st, err_flags);
+                if (rc2) return rc2;
             }
         }
     }

@@ -153,6 +153,18 @@ int launch_sampler_step(bool coarse, bool tail, const StepArgs& a, hipStream_t s
 
 // scratch: device buffer of at least rev_scratch_bytes(L) for the reverse-mode grad kernel (required when that kernel is
 // selected; mlp_uses_rev() tells)
+// importance_sample (udf_renderer_blending.py:802-841) as ONE launch (udf_mlp_kernel.inc, IS instantiations): the sampler steps and the MLP passes between
+// them.  Returns EMAP_OK, an error, or IS_NOT_FUSED (> 0: shape not covered - the caller runs the launch chain; nothing was enqueued).
+struct IsLaunch {
+    const float *rays_o, *rays_d, *near, *far, *t_rand;   // t_rand may be null
+    float* sample_dist;            // written (ray 0's wave)
+    const float* udf_coarse;       // (N, Sc)
+    float* z_final;                // (N, Sc + steps * m)
+    int32_t N, Sc, m, steps;
+};
+constexpr int IS_NOT_FUSED = 1;
+int launch_importance(const NetLayout& L, const void* packed, int prec, const IsLaunch& q, hipStream_t st, int32_t* err_flags);
+int set_fused_sampling(int on);    // process-wide switch (tests, A/B): returns the previous value
 int launch_mlp(const NetLayout& L, const void* packed, int prec, const PointSource& src, int64_t P,
                float* udf, float* grad3, hipStream_t st, int32_t* err_flags = nullptr, void* scratch = nullptr);
 int launch_null_direction(const float* g, int64_t n, int k, float* dir, hipStream_t st);

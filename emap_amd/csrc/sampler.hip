@@ -17,196 +17,14 @@
 
 namespace emap {
 
-constexpr int MAXS = 256;  // max samples per ray handled by the per-ray kernels
+#include "sampler_dev.inc"
 
-#define FADD(a, b) __fadd_rn((a), (b))
-#define FSUB(a, b) __fsub_rn((a), (b))
-#define FMUL(a, b) __fmul_rn((a), (b))
-#define FDIV(a, b) __fdiv_rn((a), (b))
-
-__device__ __forceinline__ float sigmoidf_(float x) { return FDIV(1.0f, FADD(1.0f, expf(-x))); }
-__device__ __forceinline__ float clipf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
-__device__ __forceinline__ float relu_(float x) { return fmaxf(x, 0.0f); }
-
-// Cross-lane fp64 scans on the DPP network instead of ds_bpermute shuffles (round 4: a __shfl_up / __shfl_xor of a double is two LDS-crossbar
-// round trips of ~130 cycles, six steps per scan, three scans and a sum per importance-sampling step: profiles/r04_sampler_timeline_*.txt).
-// dpp_d: both halves of a double through v_mov_b32_dpp with the same control; lanes without a source keep `ident`.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_d(double ident, double v) {
-    const unsigned long long iv = __builtin_bit_cast(unsigned long long, ident), sv = __builtin_bit_cast(unsigned long long, v);
-    const int lo = __builtin_amdgcn_update_dpp((int)(unsigned)iv, (int)(unsigned)sv, CTRL, ROW_MASK, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp((int)(unsigned)(iv >> 32), (int)(unsigned)(sv >> 32), CTRL, ROW_MASK, 0xf, false);
-    return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo);
-}
-// inclusive scan over the 64 lanes: row_shr 1, 2, 4, 8 inside the rows of 16, then row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3
-// (the gfx9 wave64 sequence); lane 63 ends with the total
-template <bool MUL>
-__device__ __forceinline__ double wave_scan_incl_d(double v) {
-    const double id = MUL ? 1.0 : 0.0;
-#define EMAP_SCAN_STEP(CTRL, RM) { const double o_ = dpp_d<CTRL, RM>(id, v); v = MUL ? v * o_ : v + o_; }
-    EMAP_SCAN_STEP(0x111, 0xf)   // row_shr:1
-    EMAP_SCAN_STEP(0x112, 0xf)   // row_shr:2
-    EMAP_SCAN_STEP(0x114, 0xf)   // row_shr:4
-    EMAP_SCAN_STEP(0x118, 0xf)   // row_shr:8
-    EMAP_SCAN_STEP(0x142, 0xa)   // row_bcast:15 -> rows 1, 3
-    EMAP_SCAN_STEP(0x143, 0xc)   // row_bcast:31 -> rows 2, 3
-#undef EMAP_SCAN_STEP
-    return v;
-}
-__device__ __forceinline__ double readlane63_d(double v) {
-    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), 63);
-    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
-}
-__device__ __forceinline__ double wave_sum_d(double v) { return readlane63_d(wave_scan_incl_d<false>(v)); }
-
-// Exclusive prefix product (MUL=true) or inclusive prefix sum (MUL=false) over n <= MAXS values in
-// LDS, fp64 accumulation, fp32 outputs.  Each lane owns a contiguous chunk of C = ceil(n/64) values.
-//   MUL : out[i] = prod_{k<i} in[k]   (cumprod(cat([1, x]))[:-1], udf_renderer_blending.py:308-319)
-//   SUM : out[i] = sum_{k<=i} in[k]   (cumsum, :75)
-template <bool MUL>
-__device__ __forceinline__ void wave_scan(const float* in, float* out, int n, int lane) {
-    const int C = (n + 63) >> 6;
-    const int b = lane * C;
-    double loc = MUL ? 1.0 : 0.0;
-    for (int i = 0; i < C; ++i) {
-        const int e = b + i;
-        if (e < n) loc = MUL ? loc * (double)in[e] : loc + (double)in[e];
-    }
-    // exclusive scan of the chunk totals across lanes: inclusive scan on the DPP network, shifted by one lane (wave_shr:1, lane 0 keeps the identity)
-    const double inc = wave_scan_incl_d<MUL>(loc);
-    const double pre = dpp_d<0x138, 0xf>(MUL ? 1.0 : 0.0, inc);
-    double run = pre;
-    for (int i = 0; i < C; ++i) {
-        const int e = b + i;
-        if (e < n) {
-            if (MUL) {
-                out[e] = (float)run;
-                run *= (double)in[e];
-            } else {
-                run += (double)in[e];
-                out[e] = (float)run;
-            }
-        }
-    }
-}
-
-// lane l <- lane l+1 (wave_shl:1); lane 63 keeps `ident`
-__device__ __forceinline__ float dpp_next_f(float ident, float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, ident), __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
-}
-// exclusive prefix product over the ray, registers in / out: lane l holds samples [l C, (l+1) C) - wave_scan<true>'s arithmetic on the same chunks
-template <int C>
-__device__ __forceinline__ void ray_prefix_prod(const float (&in)[C], const bool (&ok)[C], float (&out)[C]) {
-    double loc = 1.0;
-#pragma unroll
-    for (int i = 0; i < C; ++i) if (ok[i]) loc *= (double)in[i];
-    const double inc = wave_scan_incl_d<true>(loc);
-    double run = dpp_d<0x138, 0xf>(1.0, inc);
-#pragma unroll
-    for (int i = 0; i < C; ++i) { out[i] = (float)run; if (ok[i]) run *= (double)in[i]; }
-}
-
-// lane l <- lane l-1 (wave_shr:1); lane 0 keeps `ident`
-__device__ __forceinline__ float dpp_prev_f(float ident, float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, ident), __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
-}
-// inclusive prefix sum over the ray, registers in / out: wave_scan<false>'s arithmetic on chunks of C
-template <int C>
-__device__ __forceinline__ void ray_prefix_sum(const float (&in)[C], const bool (&ok)[C], float (&out)[C]) {
-    double loc = 0.0;
-#pragma unroll
-    for (int i = 0; i < C; ++i) if (ok[i]) loc += (double)in[i];
-    const double inc = wave_scan_incl_d<false>(loc);
-    double run = dpp_d<0x138, 0xf>(0.0, inc);
-#pragma unroll
-    for (int i = 0; i < C; ++i) { if (ok[i]) run += (double)in[i]; out[i] = (float)run; }
-}
-
-// torch.linspace(start, end, steps)[i] for fp32 (ATen RangeFactories: step = (end-start)/(steps-1),
-// first half counted up from start, second half counted down from end).
-__device__ __forceinline__ float linspace_at(float start, float end, int steps, int i) {
-    if (steps == 1) return start;
-    const float step = FDIV(FSUB(end, start), (float)(steps - 1));
-    return (i < steps / 2) ? FADD(start, FMUL(step, (float)i)) : FSUB(end, FMUL(step, (float)(steps - i - 1)));
-}
 static float linspace_at_host(float start, float end, int steps, int i) {
     if (steps == 1) return start;
     volatile float step = (end - start) / (float)(steps - 1);
     volatile float a = step * (float)i;
     volatile float b = step * (float)(steps - i - 1);
     return (i < steps / 2) ? start + a : end - b;
-}
-
-// sdf2alpha, 'numerical' branch (udf_renderer_blending.py:379-411)
-__device__ __forceinline__ float sdf2alpha(float sdf, float true_cos, float dists, float inv_s, bool anneal, float car) {
-    float iter_cos = true_cos;
-    if (anneal) {
-        const float a = FMUL(relu_(FADD(FMUL(-true_cos, 0.5f), 0.5f)), FSUB(1.0f, car));
-        const float b = FMUL(relu_(-true_cos), car);
-        iter_cos = -FADD(a, b);
-    }
-    const float h = FMUL(FMUL(iter_cos, dists), 0.5f);
-    const float est_next = FADD(sdf, h);
-    const float est_prev = FSUB(sdf, h);
-    const float prev_cdf = sigmoidf_(FMUL(est_prev, inv_s));
-    const float next_cdf = sigmoidf_(FMUL(est_next, inv_s));
-    const float p = FSUB(prev_cdf, next_cdf);
-    return clipf(FDIV(FADD(p, 1e-5f), FADD(prev_cdf, 1e-5f)), 0.0f, 1.0f);
-}
-
-// udf2logistic(udf, inv_s, gamma=1, abs_cos=1) (udf_renderer_blending.py:155-170)
-__device__ __forceinline__ float udf2logistic1(float udf, float inv_s) {
-    const float e = expf(FMUL(-inv_s, udf));
-    const float den = FADD(1.0f, e);
-    return FDIV(FMUL(inv_s, e), FMUL(den, den));
-}
-
-// ---------------------------------------------------------------------------------------------
-// sample_pdf on LDS data (bins[n], w[n-1] raw weights; scratch pdf[n], cdf[n])
-// ---------------------------------------------------------------------------------------------
-// the inverse-CDF look-up of sample_pdf (:86-109) on LDS arrays bins[n], cdf[n] (cdf[0] = 0): m samples, lane k < m each
-__device__ __forceinline__ void sample_pdf_search(const float* bins, const float* cdf, int n, int m, int lane, float* samples_out,
-                                                  int64_t* inds_out, int32_t* err, const float* u_in) {
-    const float u0 = (float)(0.0 + 0.5 / (double)m), u1 = (float)(1.0 - 0.5 / (double)m);
-    bool nan = false;
-    for (int k = lane; k < m; k += 64) {
-        const float u = u_in ? u_in[k] : linspace_at(u0, u1, m, k);
-        // searchsorted(cdf, u, right=True): first index with cdf[idx] > u
-        int lo = 0, hi = n;
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (cdf[mid] <= u) lo = mid + 1; else hi = mid;
-        }
-        const int ind = lo;
-        const int below = max(ind - 1, 0), above = min(n - 1, ind);
-        const float cb = cdf[below], ca = cdf[above], bb = bins[below], ba = bins[above];
-        float denom = FSUB(ca, cb);
-        if (denom < 1e-5f) denom = 1.0f;
-        const float t = FDIV(FSUB(u, cb), denom);
-        const float s = FADD(bb, FMUL(t, FSUB(ba, bb)));
-        samples_out[k] = s;
-        if (inds_out) inds_out[k] = ind;
-        nan |= (s != s);
-    }
-    if (err && __any(nan)) { if (lane == 0) atomicOr(err, EMAP_F_NAN_SAMPLES); }
-}
-
-// u_in (optional, m values of this ray): the caller's uniform draws - sample_pdf(det=False), :84-85 - instead of the deterministic grid
-__device__ __forceinline__ void sample_pdf_wave(const float* bins, const float* w, float* pdf, float* cdf, int n, int m,
-                                                int lane, float* samples_out, int64_t* inds_out, int32_t* err, const float* u_in = nullptr) {
-    const int nw = n - 1;
-    double part = 0.0;
-    for (int e = lane; e < nw; e += 64) {
-        const float we = FADD(w[e], 1e-5f);
-        pdf[e] = we;
-        part += (double)we;
-    }
-    const float total = (float)wave_sum_d(part);
-    for (int e = lane; e < nw; e += 64) pdf[e] = FDIV(pdf[e], total);
-    wave_scan<false>(pdf, cdf + 1, nw, lane);
-    if (lane == 0) cdf[0] = 0.0f;
-    sample_pdf_search(bins, cdf, n, m, lane, samples_out, inds_out, err, u_in);
 }
 
 __global__ __launch_bounds__(64) void sample_pdf_kernel(const float* bins, const float* weights, int N, int n, int m,
@@ -218,97 +36,6 @@ __global__ __launch_bounds__(64) void sample_pdf_kernel(const float* bins, const
     __syncthreads();
     sample_pdf_wave(s_bins, s_w, s_pdf, s_cdf, n, m, lane, samples + (size_t)ray * m, inds ? inds + (size_t)ray * m : nullptr, err,
                     u ? u + (size_t)ray * m : nullptr);
-}
-
-// ---------------------------------------------------------------------------------------------
-// up_sample_unbias (udf_renderer_blending.py:228-353) -> z_new (N,m)
-// ---------------------------------------------------------------------------------------------
-struct UpsampleScratch { float a[MAXS], d[MAXS + 1]; };      // a: staging of the merge, d: cdf of sample_pdf
-
-// the whole of up_sample_unbias on the LDS lists s_z, s_u (n entries, filled and synchronised by the caller); the m new samples go to
-// samples_out (global or LDS), their searchsorted indices to inds_out (may be null).
-// Round 5: between the sorted lists (which merge and searchsorted need in LDS) and the cdf (ditto) everything lives in REGISTERS - lane l
-// holds the C consecutive samples [l C, (l+1) C) and the intervals that start at them, neighbours come over the DPP network, the three scans
-// run on the same chunks as the LDS scans did.  Same expressions, same results (the fp64 sum of the weights is exact in any order: floats
-// between 1e-5 and ~1); rounds 1-4 made eight passes over six LDS arrays with a barrier after each.
-template <int C>
-__device__ __forceinline__ void upsample_body_c(float ox, float oy, float oz, float dx, float dy, float dz, float sd, const float* s_z,
-                                                const float* s_u, UpsampleScratch& w, int n, int m, float inv_s, float beta, float gamma,
-                                                int lane, float* samples_out, int64_t* inds_out, int32_t* err) {
-    float z[C + 1], u[C + 1], rad[C + 1], tc[C];
-    bool ok[C], oki[C];            // sample e exists / interval [e, e+1] exists
-#pragma unroll
-    for (int i = 0; i < C; ++i) {
-        const int e = lane * C + i;
-        ok[i] = e < n; oki[i] = e < n - 1;
-        const int ec = ok[i] ? e : n - 1;
-        z[i] = s_z[ec]; u[i] = s_u[ec];
-    }
-    z[C] = dpp_next_f(0.f, z[0]);          // sample e+1 of a lane's last sample is the next lane's first
-    u[C] = dpp_next_f(0.f, u[0]);
-#pragma unroll
-    for (int i = 0; i < C; ++i) {
-        const float px = FADD(ox, FMUL(dx, z[i])), py = FADD(oy, FMUL(dy, z[i])), pz = FADD(oz, FMUL(dz, z[i]));
-        rad[i] = sqrtf(FADD(FADD(FMUL(px, px), FMUL(py, py)), FMUL(pz, pz)));  // :249
-    }
-    rad[C] = dpp_next_f(0.f, rad[0]);
-    // true_cos over intervals (:279)
-#pragma unroll
-    for (int i = 0; i < C; ++i) tc[i] = FDIV(FSUB(u[i + 1], u[i]), FADD(FSUB(z[i + 1], z[i]), 1e-5f));
-    const float tc_left = dpp_prev_f(0.f, tc[C - 1]);      // true_cos of the interval that ENDS at this lane's first sample
-    float av[C], sb[C];
-#pragma unroll
-    for (int i = 0; i < C; ++i) {
-        const int e = lane * C + i;
-        const float tcp = i ? tc[i ? i - 1 : 0] : tc_left;
-        const float dists_raw = oki[i] ? FSUB(z[i + 1], z[i]) : sd;                       // :254-263
-        const float vis_mask = (e == 0) ? 1.0f : ((tcp < 0.05f) ? 1.0f : 0.0f);           // :293-300
-        const float raw_occ = udf2logistic1(u[i], beta);                                  // :303
-        const float alpha_occ = FSUB(1.0f, expf(FMUL(FMUL(-relu_(raw_occ), gamma), dists_raw)));  // :305
-        av[i] = FADD(clipf(FADD(FSUB(1.0f, alpha_occ), vis_mask), 0.0f, 1.0f), 1e-7f);    // :312
-    }
-    ray_prefix_prod<C>(av, ok, sb);        // vis_prob (:308-319)
-    float alpha[C];
-#pragma unroll
-    for (int i = 0; i < C; ++i) {
-        const int e = lane * C + i;
-        const float tcp = i ? tc[i ? i - 1 : 0] : tc_left;
-        const float cv = -fabsf(tc[i]);
-        const float pcv = (e == 0) ? 0.0f : -fabsf(tcp);
-        const bool inside = (rad[i] < 1.0f) | (rad[i + 1] < 1.0f);                        // :250
-        float cos_val = clipf(fminf(pcv, cv), -1e3f, 0.0f);                               // :284-290
-        cos_val = inside ? cos_val : FMUL(cos_val, 0.0f);
-        const float mid_udf = FMUL(FADD(u[i], u[i + 1]), 0.5f);
-        const float dists = FSUB(z[i + 1], z[i]);
-        const float ap = sdf2alpha(mid_udf, cos_val, dists, inv_s, false, 0.f);           // :327-330
-        const float am = sdf2alpha(-mid_udf, cos_val, dists, inv_s, false, 0.f);
-        alpha[i] = FADD(FMUL(ap, sb[i]), FMUL(am, FSUB(1.0f, sb[i])));                    // :331
-        av[i] = FADD(FSUB(1.0f, alpha[i]), 1e-7f);
-    }
-    ray_prefix_prod<C>(av, oki, sb);       // transmittance (:334-343)
-    // sample_pdf (:69-109) on the weights alpha * T of the n - 1 intervals
-    double part = 0.0;
-#pragma unroll
-    for (int i = 0; i < C; ++i) {
-        av[i] = FADD(FMUL(alpha[i], sb[i]), 1e-5f);
-        if (oki[i]) part += (double)av[i];
-    }
-    const float total = (float)wave_sum_d(part);
-#pragma unroll
-    for (int i = 0; i < C; ++i) av[i] = FDIV(av[i], total);
-    ray_prefix_sum<C>(av, oki, sb);
-#pragma unroll
-    for (int i = 0; i < C; ++i) if (oki[i]) w.d[lane * C + i + 1] = sb[i];
-    if (lane == 0) w.d[0] = 0.0f;
-    sample_pdf_search(s_z, w.d, n, m, lane, samples_out, inds_out, err, nullptr);
-}
-
-__device__ __forceinline__ void upsample_body(float ox, float oy, float oz, float dx, float dy, float dz, float sd, const float* s_z,
-                                              const float* s_u, UpsampleScratch& w, int n, int m, float inv_s, float beta, float gamma,
-                                              int lane, float* samples_out, int64_t* inds_out, int32_t* err) {
-    if (n <= 64) upsample_body_c<1>(ox, oy, oz, dx, dy, dz, sd, s_z, s_u, w, n, m, inv_s, beta, gamma, lane, samples_out, inds_out, err);
-    else if (n <= 128) upsample_body_c<2>(ox, oy, oz, dx, dy, dz, sd, s_z, s_u, w, n, m, inv_s, beta, gamma, lane, samples_out, inds_out, err);
-    else upsample_body_c<4>(ox, oy, oz, dx, dy, dz, sd, s_z, s_u, w, n, m, inv_s, beta, gamma, lane, samples_out, inds_out, err);
 }
 
 __global__ __launch_bounds__(64) void upsample_kernel(const float* rays_o, const float* rays_d, const float* z,
@@ -334,20 +61,6 @@ __global__ __launch_bounds__(64) void upsample_kernel(const float* rays_o, const
 // cat_z_vals: merge two sorted lists (stable: old samples first on ties), gather udf
 // (udf_renderer_blending.py:361-375)
 // ---------------------------------------------------------------------------------------------
-// stable rank-merge of the sorted LDS lists s_z[n] (old) and s_n[m] (new): element e of cat([old, new]) goes to rank(e)
-__device__ __forceinline__ int merge_rank(const float* s_z, const float* s_n, int n, int m, int e, float& v) {
-    if (e < n) {
-        v = s_z[e];
-        int lo = 0, hi = m;  // # new elements strictly less than v
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_n[mid] < v) lo = mid + 1; else hi = mid; }
-        return e + lo;
-    }
-    v = s_n[e - n];
-    int lo = 0, hi = n;  // # old elements <= v
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_z[mid] <= v) lo = mid + 1; else hi = mid; }
-    return (e - n) + lo;
-}
-
 __global__ __launch_bounds__(64) void merge_kernel(const float* z, const float* z_new, const float* udf,
                                                    const float* udf_new, int N, int n, int m, float* z_out,
                                                    float* udf_out, int64_t* perm) {

@@ -12,4 +12,7 @@ int launch_vjp_sweep_bf16(const NetLayout& L, const void* packed, const PointSou
     return launch_vjp_sweep_mode<EMAP_PREC_BF16>(L, packed, src, P, tile0, n_tiles, d_udf, d_grad, V, stash_a, stash_z, stash_s, grid,
                                                  absmax, ldot, st, err);
 }
+int launch_is_bf16(const NetLayout& L, const void* packed, const IsLaunch& q, hipStream_t st, int32_t* err) {
+    return launch_is_mode<EMAP_PREC_BF16>(L, packed, q, st, err);
+}
 }  // namespace emap

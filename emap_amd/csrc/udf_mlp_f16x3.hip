@@ -12,4 +12,7 @@ int launch_vjp_sweep_f16x3(const NetLayout& L, const void* packed, const PointSo
     return launch_vjp_sweep_mode<EMAP_PREC_F16X3>(L, packed, src, P, tile0, n_tiles, d_udf, d_grad, V, stash_a, stash_z, stash_s, grid,
                                                  absmax, ldot, st, err);
 }
+int launch_is_f16x3(const NetLayout& L, const void* packed, const IsLaunch& q, hipStream_t st, int32_t* err) {
+    return launch_is_mode<EMAP_PREC_F16X3>(L, packed, q, st, err);
+}
 }  // namespace emap

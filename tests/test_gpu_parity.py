@@ -632,6 +632,36 @@ def test_render_with_more_than_128_samples_on_its_own_z_vals_vs_oracle(ns, ni, s
         assert errs[dt]["gradient_error"] <= 1e-5
 
 
+@pytest.mark.parametrize("netname,N", [("d8w256L10", 512), ("d8w256L10", 700), ("d8w256L10", 100), ("d8w256L10", 33), ("d8w256L10", 1024),
+                                       ("d4w128L10", 512), ("d4w128L10", 37)])
+def test_fused_importance_sampling_equals_the_launch_chain_bit_for_bit(netname, N):
+    """ABI v8: importance_sample (udf_renderer_blending.py:802-841) as ONE launch - the sampler steps run inside the workgroups of the narrow MLP
+    passes, the ray's lists stay in LDS (udf_mlp_kernel.inc, IS) - against the chain of 2 K - 1 launches it replaces
+    (emap_set_fused_sampling(0)): z_vals and every rendered quantity identical bit for bit, for every workgroup geometry the launcher picks
+    (2 rays x 8 waves, 2 x 4, 1 x 8 / 1 x 4, odd ray counts), with and without the per-ray jitter."""
+    from emap_amd import synthetic
+    net, _, _ = mk(netname, "f16x3")
+    r = mk_renderer(net, 64, 64, 4)
+    ro, rd, near, far, ds = [v.to(DEV) for v in synthetic.make_rays(N, seed=5)]
+    tr = synthetic.make_t_rand(N).to(DEV)
+    L = _lib.lib()
+    outs = {}
+    try:
+        for fused in (1, 0):
+            L.emap_set_fused_sampling(fused)
+            with torch.no_grad():
+                o1 = r.render(ro, rd, near, far, ds, cos_anneal_ratio=1.0, flip_saturation=0.9, t_rand=tr)
+                o2 = r.render(ro, rd, near, far, ds, cos_anneal_ratio=1.0, perturb_overwrite=0, flip_saturation=0.9)
+            torch.cuda.synchronize()
+            r.check_errors()
+            outs[fused] = {tag + k: v.clone() for tag, o in (("jitter.", o1), ("plain.", o2)) for k, v in o.items() if isinstance(v, torch.Tensor)}
+    finally:
+        L.emap_set_fused_sampling(1)
+    assert set(outs[0]) == set(outs[1]) and "jitter.z_vals" in outs[1] and "plain.z_vals" in outs[1]
+    for k in outs[1]:
+        assert torch.equal(outs[1][k], outs[0][k]), k
+
+
 def test_perturb_path_and_float_near_far():
     g = load_golden("g7_perturb")
     net, _, _ = mk("d4w128L10", "f16x3")
