@@ -633,7 +633,7 @@ def test_render_with_more_than_128_samples_on_its_own_z_vals_vs_oracle(ns, ni, s
 
 
 @pytest.mark.parametrize("netname,N", [("d8w256L10", 512), ("d8w256L10", 700), ("d8w256L10", 100), ("d8w256L10", 33), ("d8w256L10", 1024),
-                                       ("d4w128L10", 512), ("d4w128L10", 37)])
+                                       ("d8w256L10", 1), ("d8w256L10", 2047), ("d4w128L10", 512), ("d4w128L10", 37)])
 def test_fused_importance_sampling_equals_the_launch_chain_bit_for_bit(netname, N):
     """ABI v8: importance_sample (udf_renderer_blending.py:802-841) as ONE launch - the sampler steps run inside the workgroups of the narrow MLP
     passes, the ray's lists stay in LDS (udf_mlp_kernel.inc, IS) - against the chain of 2 K - 1 launches it replaces
