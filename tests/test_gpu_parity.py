@@ -635,12 +635,21 @@ def test_render_with_more_than_128_samples_on_its_own_z_vals_vs_oracle(ns, ni, s
 @pytest.mark.parametrize("netname,N", [("d8w256L10", 512), ("d8w256L10", 700), ("d8w256L10", 100), ("d8w256L10", 33), ("d8w256L10", 1024),
                                        ("d8w256L10", 1), ("d8w256L10", 2047), ("d4w128L10", 512), ("d4w128L10", 37)])
 def test_fused_importance_sampling_equals_the_launch_chain_bit_for_bit(netname, N):
+    _fused_vs_chain(netname, N, "f16x3")
+
+
+@pytest.mark.parametrize("prec", ["f16x3m", "f16x3e", "bf16x3", "f16", "bf16"])
+def test_fused_importance_sampling_in_every_precision_mode(prec):
+    _fused_vs_chain("d8w256L10", 512, prec)
+
+
+def _fused_vs_chain(netname, N, prec):
     """ABI v8: importance_sample (udf_renderer_blending.py:802-841) as ONE launch - the sampler steps run inside the workgroups of the narrow MLP
     passes, the ray's lists stay in LDS (udf_mlp_kernel.inc, IS) - against the chain of 2 K - 1 launches it replaces
     (emap_set_fused_sampling(0)): z_vals and every rendered quantity identical bit for bit, for every workgroup geometry the launcher picks
     (2 rays x 8 waves, 2 x 4, 1 x 8 / 1 x 4, odd ray counts), with and without the per-ray jitter."""
     from emap_amd import synthetic
-    net, _, _ = mk(netname, "f16x3")
+    net, _, _ = mk(netname, prec)
     r = mk_renderer(net, 64, 64, 4)
     ro, rd, near, far, ds = [v.to(DEV) for v in synthetic.make_rays(N, seed=5)]
     tr = synthetic.make_t_rand(N).to(DEV)
