@@ -898,9 +898,8 @@ def main():
             except Exception as e:  # the baseline must never take the GPU line down
                 line["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(line), flush=True)
-    if trainer is not None and getattr(trainer, "_oneshot", None) is not None:
-        trainer._oneshot.check()        # a launch that gave up on a peer must fail the bench, not report a number
-        trainer._oneshot.close()
+    if trainer is not None:
+        trainer.close()                 # a launch that gave up on a peer must fail the bench, not report a number
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -23,7 +23,7 @@ PREC_F16X3E = 5    # f16x3 with f16 cross terms in both sweeps of the value+grad
 PRECISIONS = {"bf16": PREC_BF16, "bf16x3": PREC_BF16X3, "f16": PREC_F16, "f16x3": PREC_F16X3, "f16x3m": PREC_F16X3M, "f16x3e": PREC_F16X3E}
 UDF_TYPES = {"abs": 0, "square": 1, "sdf": 2}
 MAX_LIN = 12
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 F_NAN_SAMPLES = 1
 F_NAN_GRADERR = 2
@@ -123,6 +123,7 @@ SYMBOLS = {
     "emap_ar_free": (C.c_int, [_P]),
     "emap_ar_allreduce_sum": (C.c_int, [_P, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_size_t, _P]),
     "emap_ar_error": (C.c_int, [_P, C.POINTER(C.c_int)]),
+    "emap_ar_set_timeout_ms": (C.c_int, [C.c_int64]),
     "emap_profile_enable": (C.c_int, [C.c_int]),
     "emap_profile_read": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "emap_profile_read_kernel": (C.c_int, [C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]),

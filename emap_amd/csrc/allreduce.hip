@@ -18,8 +18,11 @@
 //   1  copy its gradient bucket into its staging buffer t & 1;
 //   2  the last workgroup to finish that (device-scope counter behind a system-scope fence) publishes flag = t with a
 //      system-scope RELEASE store;
-//   3  every workgroup ACQUIRE-polls the flags of all peers until they show >= t (bounded: ~2 s of s_memrealtime, then the error
-//      word is set and the launch finishes - a dead peer must not hang the GPU);
+//   3  every workgroup ACQUIRE-polls the flags of all peers until they show >= t (bounded by s_memrealtime: emap_ar_set_timeout_ms,
+//      default 10 s, 6x that for the first two launches whose peers may still be loading code objects / allocating workspaces;
+//      a dead peer must not hang the GPU).  A time-out is LOUD: the sticky error word is set AND the workgroup writes NaN instead
+//      of a partial sum, so every consumer of the bucket (Adam, the loss) turns NaN on this rank - ranks cannot silently apply
+//      different gradients;
 //   4  out[i] = sum over ranks r = 0 .. R-1, in that order, of staging_r[t & 1][i]  (16-byte loads straight from the peers);
 //   5  the last workgroup to finish stores step = t for the next launch.
 // Double buffering makes one flag wait per launch enough: a rank overwrites buffer b again in launch t + 2, which it enters only
@@ -52,6 +55,7 @@ struct ArArgs {
     char* region[AR_MAX_RANKS];        // region of rank r as mapped into this process (region[rank] = own)
     int rank, world;
     long long stage_floats;            // capacity of one staging buffer
+    long long timeout_ticks;           // bound of one flag wait in s_memrealtime ticks (100 MHz)
 };
 
 __device__ __forceinline__ float* ar_staging(char* region, long long stage_floats, uint32_t b) {
@@ -84,6 +88,9 @@ __global__ __launch_bounds__(AR_THREADS) void allreduce_oneshot_kernel(const ArA
         }
     }
     // ---- 3: wait for every rank's buffer b of step t (own included: its last workgroup may still be copying) ----
+    __shared__ int timed_out;
+    if (threadIdx.x == 0) timed_out = 0;
+    __syncthreads();
     if ((int)threadIdx.x < a.world) {
         ArCtrl* const pc = reinterpret_cast<ArCtrl*>(a.region[threadIdx.x]);
         const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();      // 100 MHz
@@ -91,15 +98,21 @@ __global__ __launch_bounds__(AR_THREADS) void allreduce_oneshot_kernel(const ArA
         while (true) {
             const uint32_t f = __hip_atomic_load(&pc->flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
             if ((int32_t)(f - t) >= 0) { ok = true; break; }
-            if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > 200000000ll) break;      // 2 s
+            if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > (t <= 2u ? 6 * a.timeout_ticks : a.timeout_ticks)) break;
             __builtin_amdgcn_s_sleep(8);
         }
-        if (!ok) __hip_atomic_store(&me->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (!ok) {
+            __hip_atomic_store(&me->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            timed_out = 1;
+        }
     }
     __syncthreads();
     __atomic_thread_fence(__ATOMIC_ACQUIRE);     // (every thread's later loads are ordered behind the polls of its workgroup)
-    // ---- 4: sum in rank order ----
-    {
+    // ---- 4: sum in rank order (a peer that never arrived: poison this workgroup's share instead of summing stale buffers) ----
+    if (timed_out) {
+        const float qnan = __builtin_nanf("");
+        for (long long i = tid; i < a.n; i += nth) a.data[i] = qnan;
+    } else {
         for (long long i = tid; i < n4; i += nth) {
             ar_f4 acc = {0.f, 0.f, 0.f, 0.f};
             for (int r = 0; r < a.world; ++r)
@@ -129,6 +142,14 @@ using namespace emap;
 
 extern "C" {
 
+static long long g_ar_timeout_ticks = 1000000000ll;     // 10 s of the 100 MHz s_memrealtime counter
+
+int emap_ar_set_timeout_ms(int64_t ms) {
+    if (ms < 1 || ms > 600000) { set_error("ar_set_timeout_ms: %lld ms is outside [1, 600000]", (long long)ms); return EMAP_E_INVALID; }
+    g_ar_timeout_ticks = (long long)ms * 100000ll;
+    return EMAP_OK;
+}
+
 int emap_ar_local_bytes(int64_t n_floats, size_t* bytes) {
     if (!bytes || n_floats <= 0 || n_floats > (64ll << 20) / 4) { set_error("ar_local_bytes: n_floats must be in (0, 16 Mi] (a latency-bound bucket; use RCCL above that)"); return EMAP_E_INVALID; }
     const size_t stage = ((size_t)n_floats * 4 + 255) & ~(size_t)255;
@@ -140,11 +161,13 @@ int emap_ar_alloc(size_t bytes, void** region, void* ipc_handle64) {
     if (!region || !ipc_handle64 || bytes < AR_CTRL_BYTES) { set_error("ar_alloc: bad arguments"); return EMAP_E_INVALID; }
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
     void* p = nullptr;
-    // uncached: flags and staging are read by peers while kernels run on both sides; falls back to a plain allocation (the kernel's
-    // system-scope release / acquire pairs are what the memory model requires either way)
+    // uncached / fine-grained: flags and staging are read by peers WHILE kernels run on both sides.  There is no fall-back to a plain
+    // hipMalloc: coarse-grained memory gives no cross-device visibility guarantee during a running kernel, whatever scope the
+    // atomics name - the failure would surface as time-outs.  Callers fall back to RCCL instead (Trainer(allreduce="rccl")).
     if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached) != hipSuccess) {
         (void)hipGetLastError();
-        if (hipMalloc(&p, bytes) != hipSuccess) { set_error("ar_alloc: allocation of %zu bytes failed", bytes); (void)hipGetLastError(); return EMAP_E_LAUNCH; }
+        set_error("ar_alloc: fine-grained (uncached) allocation of %zu bytes failed; use the RCCL transport", bytes);
+        return EMAP_E_LAUNCH;
     }
     if (hipMemset(p, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { set_error("ar_alloc: memset failed"); (void)hipFree(p); return EMAP_E_LAUNCH; }
     hipIpcMemHandle_t h;
@@ -187,13 +210,14 @@ int emap_ar_allreduce_sum(float* data, int64_t n, int rank, int world, void* con
     ArArgs a;
     a.data = data; a.n = n; a.rank = rank; a.world = world;
     a.stage_floats = (long long)((region_bytes - AR_CTRL_BYTES) / 2 / 4);
+    a.timeout_ticks = g_ar_timeout_ticks;
     for (int r = 0; r < AR_MAX_RANKS; ++r) a.region[r] = (r < world) ? static_cast<char*>(regions_host[r]) : nullptr;
     for (int r = 0; r < world; ++r) if (!a.region[r]) { set_error("ar_allreduce_sum: region of rank %d is null", r); return EMAP_E_INVALID; }
     hipLaunchKernelGGL(allreduce_oneshot_kernel, dim3(AR_BLOCKS), dim3(AR_THREADS), 0, static_cast<hipStream_t>(stream), a);
     return check_launch("ar_allreduce_sum");
 }
 
-/* error word of the own region (host read: synchronises the device) - 1 if a peer's flag did not arrive within ~2 s in some launch */
+/* error word of the own region (host read: synchronises the device) - 1 if a peer's flag did not arrive within the time-out in some launch */
 int emap_ar_error(void* region, int* error_host) {
     if (!region || !error_host) { set_error("ar_error: null pointer"); return EMAP_E_INVALID; }
     uint32_t e = 0;

@@ -153,7 +153,11 @@ def train_wrapper(orig_train, mod=None, fused_adam: bool = True, defer_scalars: 
         runner's ``torch.optim.Adam`` over the same groups: one launch instead of 32 x 6) reads them in place;
       * the tensorboard writer the method creates defers device scalars (``DeferredScalarWriter``, flushed every ``report_freq`` steps);
       * ``loss.backward()`` runs on the calling thread (``torch.autograd.set_multithreading_enabled(False)`` for the duration of the loop).
-    What stays: the progress bar's ``loss.item()`` / ``format(psnr)`` (runner_udf.py:164) - one wait for the forward per step."""
+    What stays: the progress bar's ``loss.item()`` / ``format(psnr)`` (runner_udf.py:164) - one wait for the forward per step.
+    Side effects that outlive the call: ``self.optimizer`` STAYS the FusedAdam - the runner's later ``save_checkpoint`` /
+    a second ``train_udf`` must see the moments of the steps taken here, and its ``state_dict()`` is in ``torch.optim.Adam``'s layout
+    (a stock Adam over the same groups loads it).  Everything else is restored in the ``finally`` block, pending tensorboard rows are
+    flushed there too - also when the loop raises."""
     def train_udf(self, *a, **k):
         import torch
         from .parallel import FusedAdam

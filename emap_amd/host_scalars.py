@@ -7,8 +7,12 @@ stream synchronisation that waits for the whole forward render enqueued just bef
 ``UDFRendererBlending.host_mirror_scalars`` the renderer computes them BEFORE it enqueues the forward, starts an asynchronous copy into
 a pinned buffer and hands out ``HostScalar`` tensors: ordinary device tensors (same storage, attached to autograd, every torch op
 works as before) whose HOST reads - ``item()``, ``float()``, ``format()``, comparisons with python numbers, ``mean()`` of the
-constant-expanded ``variance`` - are answered from the pinned copy after waiting for THAT copy only.  Values are those the device
-tensor holds (the same kernels produced both); nothing is stale.
+constant-expanded ``variance`` - are answered from the pinned copy after waiting for THAT copy only.  With trainable scalars the
+pinned value is a copy of the very device value; with frozen ones (``requires_grad = False``) the device tensor comes out of the
+compositing kernel's scalar block while the mirror is a separate torch expression of the same parameter - equal up to an ulp of
+``exp``.  The first host read copies the number out of the ring slot (``_Slot.value``), so a render dict kept for longer than the
+ring is deep still answers with ITS step's value; a dict first read only after its slot was recycled falls back to the ordinary
+synchronising device read.
 """
 from __future__ import annotations
 
@@ -21,15 +25,17 @@ class HostScalar(torch.Tensor):
     __torch_function__ = torch._C._disabled_torch_function_impl      # torch ops see (and return) plain tensors: no dispatch overhead
 
     @staticmethod
-    def wrap(t: torch.Tensor, host: torch.Tensor, idx: int, event) -> "HostScalar":
+    def wrap(t: torch.Tensor, slot: "_Slot", idx: int) -> "HostScalar":
         r = t.as_subclass(HostScalar)
-        r._emap_host = (host, idx, event)
+        r._emap_host = (slot, idx)
         return r
 
     def _host_value(self) -> float:
-        host, idx, ev = self._emap_host
-        ev.synchronize()                       # the small copy only - not the stream
-        return float(host[idx])
+        slot, idx = self._emap_host
+        v = slot.read(idx)
+        if v is None:                          # the ring slot was reused before anybody read this push: the device value it is
+            return float(torch.Tensor.item(self.as_subclass(torch.Tensor).reshape(-1)[0]))
+        return v
 
     def _mirrored(self) -> bool:
         return getattr(self, "_emap_host", None) is not None
@@ -78,22 +84,42 @@ class HostScalar(torch.Tensor):
         return self._cmp(o, lambda a, b: a >= b, torch.Tensor.__ge__)
 
 
+class _Slot:
+    """One push of a ``ScalarMirror``: the pinned buffer + event it travels through and the generation of that buffer it belongs to.
+    ``read(idx)`` waits for the copy, takes ALL values out of the pinned buffer once (``value``) and answers from that copy afterwards;
+    None if the buffer has been handed to a later push before the first read."""
+
+    __slots__ = ("host", "event", "gen_ref", "gen", "n", "value")
+
+    def __init__(self, host, event, gen_ref, gen, n):
+        self.host, self.event, self.gen_ref, self.gen, self.n, self.value = host, event, gen_ref, gen, n, None
+
+    def read(self, idx: int):
+        if self.value is None:
+            if self.gen_ref[0] != self.gen:
+                return None
+            self.event.synchronize()           # the small copy only - not the stream
+            self.value = self.host[:self.n].tolist()
+        return self.value[idx]
+
+
 class ScalarMirror:
-    """Ring of pinned 4-float slots + events: ``push(values_dev)`` starts the copy on the current stream and returns (host, event)."""
+    """Ring of pinned 4-float buffers + events: ``push(values_dev)`` starts the copy on the current stream and returns its ``_Slot``."""
 
     def __init__(self, dev, depth: int = 8):
         self.dev = dev
-        self.slots = [(torch.zeros(4).pin_memory(), torch.cuda.Event()) for _ in range(depth)]
+        self.slots = [(torch.zeros(4).pin_memory(), torch.cuda.Event(), [0]) for _ in range(depth)]
         self.i = 0
 
-    def push(self, values_dev: torch.Tensor):
-        host, ev = self.slots[self.i % len(self.slots)]
+    def push(self, values_dev: torch.Tensor) -> _Slot:
+        host, ev, gen = self.slots[self.i % len(self.slots)]
         if self.i >= len(self.slots):
-            ev.synchronize()                   # the slot's previous copy (depth steps ago) - done long since
+            ev.synchronize()                   # the buffer's previous copy (depth steps ago) - done long since
         self.i += 1
+        gen[0] += 1                            # slots of earlier pushes through this buffer stop reading it
         host[:values_dev.numel()].copy_(values_dev, non_blocking=True)
         ev.record(torch.cuda.current_stream(self.dev))
-        return host, ev
+        return _Slot(host, ev, gen, gen[0], values_dev.numel())
 
 
 class MaskedSelection:

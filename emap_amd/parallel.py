@@ -94,8 +94,16 @@ class OneShotAllReduce:
                                                         _lib.stream_ptr(t.device)), "ar_allreduce_sum")
         return t
 
+    @staticmethod
+    def set_timeout_ms(ms: int):
+        """Bound of one peer wait inside the kernel (default 10 s; x6 for a region's first two launches).  Process-wide."""
+        from . import _lib
+        _lib.check(_lib.lib().emap_ar_set_timeout_ms(int(ms)), "ar_set_timeout_ms")
+
     def check(self):
-        """Raise if a launch gave up waiting for a peer (host read: synchronises)."""
+        """Raise if a launch gave up waiting for a peer (host read: synchronises).  Such a launch has also written NaN into its bucket
+        (csrc/allreduce.hip step 4), so the loss and the parameters of this rank are NaN from that step on - the time-out cannot pass
+        unnoticed even where nobody calls this."""
         import ctypes as C
         from . import _lib
         e = C.c_int()
@@ -262,6 +270,22 @@ class Trainer:
             if not p.requires_grad:
                 raise NotImplementedError("Trainer: a UDF network parameter with requires_grad=False is not supported")
         return tuple(bool(p.requires_grad) for p in self.scalars)
+
+    def check_errors(self):
+        """Host-side health check (synchronises): the renderer's device error word and - ``allreduce="oneshot"`` - the collective's
+        time-out word.  Call it wherever the loop reads the loss anyway (bench.py and scripts/train_synthetic.py do, every report)."""
+        self.r.check_errors()
+        if self._oneshot is not None:
+            self._oneshot.check()
+
+    def close(self):
+        """Check for a timed-out collective one last time and unmap the peers' regions (collective: every rank calls it)."""
+        one, self._oneshot = self._oneshot, None
+        if one is not None:
+            try:
+                one.check()
+            finally:
+                one.close()
 
     def refresh_trainable_mask(self, capturing: bool = False):
         """Mirror `requires_grad` of variance / beta / gamma (runner_udf.py:141-154 flips them during training) into the device mask
@@ -545,14 +569,25 @@ class FusedAdam(torch.optim.Optimizer):
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
-        groups = [g for g in self.param_groups if len(g["params"])]
-        if not groups:
+        if not self._live_groups():
             raise ValueError("FusedAdam: no parameters")
-        self._geo_group = groups[0]
-        self._tail_groups = groups[1:]
         if len({g["lr"] for g in self._tail_groups}) > 1:
             raise ValueError("FusedAdam: the groups behind the first one must share one learning rate (the runner's do)")
         self._flat = None
+
+    # The groups are looked up in ``self.param_groups`` at every use: ``Optimizer.load_state_dict`` / ``__setstate__`` REPLACE the group
+    # dicts, and the runner's schedulers write ``lr`` into whatever dicts ``optimizer.param_groups`` holds at that time
+    # (runner_base.py:128-150) - a reference bound in __init__ would keep reading the construction-time learning rate after a resume.
+    def _live_groups(self):
+        return [g for g in self.param_groups if len(g["params"])]
+
+    @property
+    def _geo_group(self):
+        return self._live_groups()[0]
+
+    @property
+    def _tail_groups(self):
+        return self._live_groups()[1:]
 
     @classmethod
     def from_adam(cls, adam: torch.optim.Optimizer) -> "FusedAdam":
@@ -673,15 +708,17 @@ class FusedAdam(torch.optim.Optimizer):
         if flags != self._flags:                # rare: a set_trainable() of the runner
             self._tail_mask[:len(flags)].copy_(torch.tensor(flags))
             self._flags = flags
-        lr_tail = self._tail_groups[0]["lr"] if self._tail_groups else self._geo_group["lr"]
-        b1, b2 = self._geo_group["betas"]
+        live = self._live_groups()              # the CURRENT group dicts (see _live_groups): lr is read per step
+        geo_group, tail_groups = live[0], live[1:]
+        lr_tail = tail_groups[0]["lr"] if tail_groups else geo_group["lr"]
+        b1, b2 = geo_group["betas"]
         L, st = _lib.lib(), _lib.stream_ptr(dev)
         with torch.cuda.device(dev):
             if geo_ptr is None:
                 grad = torch.cat(parts)
                 _lib.check(L.emap_adam_step_masked(_lib.ptr(self._flat.data), _lib.ptr(grad), _lib.ptr(self._m), _lib.ptr(self._v),
-                                                   _lib.ptr(self._t), self._flat.numel, self._n_geo, float(self._geo_group["lr"]),
-                                                   float(lr_tail), float(b1), float(b2), float(self._geo_group["eps"]),
+                                                   _lib.ptr(self._t), self._flat.numel, self._n_geo, float(geo_group["lr"]),
+                                                   float(lr_tail), float(b1), float(b2), float(geo_group["eps"]),
                                                    _lib.ptr(self._tail_mask), _lib.ptr(self._tail_step), st), "adam_step")
             else:
                 # two launches on disjoint ranges, same arithmetic: the geometry range straight from the caller's flat gradient buffer
@@ -689,15 +726,15 @@ class FusedAdam(torch.optim.Optimizer):
                 import ctypes as C
                 ng, nt = self._n_geo, self._flat.numel - self._n_geo
                 _lib.check(L.emap_adam_step(_lib.ptr(self._flat.data), C.c_void_p(geo_ptr), _lib.ptr(self._m), _lib.ptr(self._v),
-                                            _lib.ptr(self._t), ng, ng, float(self._geo_group["lr"]), float(lr_tail), float(b1), float(b2),
-                                            float(self._geo_group["eps"]), st), "adam_step")
+                                            _lib.ptr(self._t), ng, ng, float(geo_group["lr"]), float(lr_tail), float(b1), float(b2),
+                                            float(geo_group["eps"]), st), "adam_step")
                 if nt > 0:
                     gt = torch.cat(parts)
                     if getattr(self, "_t_tail_dummy", None) is None:
                         self._t_tail_dummy = torch.zeros(1, device=dev)
                     _lib.check(L.emap_adam_step_masked(_lib.ptr(self._flat.data[ng:]), _lib.ptr(gt), _lib.ptr(self._m[ng:]), _lib.ptr(self._v[ng:]),
-                                                       _lib.ptr(self._t_tail_dummy), nt, 0, float(self._geo_group["lr"]), float(lr_tail),
-                                                       float(b1), float(b2), float(self._geo_group["eps"]), _lib.ptr(self._tail_mask),
+                                                       _lib.ptr(self._t_tail_dummy), nt, 0, float(geo_group["lr"]), float(lr_tail),
+                                                       float(b1), float(b2), float(geo_group["eps"]), _lib.ptr(self._tail_mask),
                                                        _lib.ptr(self._tail_step), st), "adam_step")
         # the in-place flat update is invisible to the per-tensor version counters UDFNetwork.packed() keys its fragment cache on
         inc = getattr(torch.autograd.graph, "increment_version", None)

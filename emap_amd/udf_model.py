@@ -88,24 +88,32 @@ class UDFNetwork(nn.Module):
     def _gvb(self):
         """(g, v, b) per layer; without weight_norm g = ||v|| so that g*v/||v|| = v."""
         # cached: the walk through nine parametrized modules costs ~0.1 ms of host time and sits on the critical path of the drop-in
-        # training step (twice per backward); valid as long as the first and last layers still hold the tensors it recorded
+        # training step (twice per backward).  Valid while EVERY layer still holds the module and parameter objects it recorded
+        # (ADVICE r5: a re-parametrised or replaced middle layer must not be packed from stale tensors) - checked through the modules'
+        # own dicts: ~50 dict lookups, a few microseconds.
         c = getattr(self, "_gvb_cache", None)
         if c is not None and self.weight_norm:
-            lin0, linl = self.lin0, getattr(self, "lin" + str(self.num_layers - 2))
-            if c[1][0] is lin0.parametrizations.weight.original1 and c[2][-1] is linl.bias and c[0][-1] is linl.parametrizations.weight.original0:
-                return c
-        gs, vs, bs = [], [], []
+            mods = self._modules
+            for name, lin, pc, pl, g, v, b in c[3]:
+                if (mods.get(name) is not lin or lin._modules.get("parametrizations") is not pc or pc._modules.get("weight") is not pl
+                        or pl._parameters.get("original0") is not g or pl._parameters.get("original1") is not v
+                        or lin._parameters.get("bias") is not b):
+                    break
+            else:
+                return c[:3]
+        gs, vs, bs, recs = [], [], [], []
         for l in range(self.num_layers - 1):
             lin = getattr(self, "lin" + str(l))
             if self.weight_norm:
                 g = lin.parametrizations.weight.original0
                 v = lin.parametrizations.weight.original1
+                recs.append(("lin" + str(l), lin, lin.parametrizations, lin.parametrizations.weight, g, v, lin.bias))
             else:
                 v = lin.weight
                 g = torch.linalg.norm(v.detach(), dim=1, keepdim=True)
             gs.append(g); vs.append(v); bs.append(lin.bias)
         if self.weight_norm:
-            self._gvb_cache = (gs, vs, bs)
+            self._gvb_cache = (gs, vs, bs, recs)
         return gs, vs, bs
 
     def net_config(self) -> _lib.NetConfig:

@@ -406,7 +406,7 @@ class UDFRendererBlending:
             gamma_out = sc[10:11]
         if pre is not None and self.host_mirror_scalars:
             from .host_scalars import HostScalar, LazyMaskable
-            s_val, beta_out, gamma_out = (HostScalar.wrap(q, mirror[0], i, mirror[1]) for i, q in enumerate((s_val, beta_out, gamma_out)))
+            s_val, beta_out, gamma_out = (HostScalar.wrap(q, mirror, i) for i, q in enumerate((s_val, beta_out, gamma_out)))
             out["udf"] = out["udf"].as_subclass(LazyMaskable)     # runner_udf.py:126 indexes a reduction of it with a boolean mask: no sync for that
         return {
             "udf": out["udf"], "edge": out["edge"], "weight_sum": out["weight_sum"], "weight_sum_fg_bg": out["weight_sum"],

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EMAP_ABI_VERSION 8
+#define EMAP_ABI_VERSION 9
 
 /* error codes */
 #define EMAP_OK 0
@@ -379,8 +379,12 @@ int emap_profile_read_clock(int which, float* mhz_host);
  *   emap_ar_allreduce_sum : data[0..n) <- sum over ranks, in place; regions_host = HOST array of `world` device pointers, entry r = the
  *                           region of rank r as mapped into THIS process (entry `rank` = the own region).  Every rank calls it in lock
  *                           step with the same n.  Graph-capturable (the step counter lives in the region).  A peer that does not
- *                           show up within ~2 s sets the error word instead of hanging the device.
- *   emap_ar_error         : host read of that error word (synchronises). */
+ *                           show up within the time-out sets the sticky error word AND makes this rank's result NaN (ABI 9: never a
+ *                           partial sum - the failure reaches every consumer of the bucket) instead of hanging the device.
+ *   emap_ar_set_timeout_ms: that time-out (ABI 9; default 10 000 ms, x6 for a region's first two launches: lazy code-object loads,
+ *                           workspace allocations and data-loader stalls skew the ranks most at start-up); process-wide, read at launch.
+ *   emap_ar_error         : host read of that error word (synchronises).
+ *   emap_ar_alloc FAILS when fine-grained memory is not available (ABI 9; no coarse-grained fall-back: use RCCL then). */
 int emap_ar_local_bytes(int64_t n_floats, size_t* bytes);
 int emap_ar_alloc(size_t bytes, void** region, void* ipc_handle64);
 int emap_ar_open(const void* ipc_handle64, void** peer_region);
@@ -388,6 +392,7 @@ int emap_ar_close(void* peer_region);
 int emap_ar_free(void* region);
 int emap_ar_allreduce_sum(float* data, int64_t n, int rank, int world, void* const* regions_host, size_t region_bytes, void* stream);
 int emap_ar_error(void* region, int* error_host);
+int emap_ar_set_timeout_ms(int64_t ms);
 
 /* host-only: torch.linspace(start, end, steps) in fp32, the grid of sample_pdf's u / the coarse z_vals */
 void emap_linspace_host(float start, float end, int steps, float* out_host);

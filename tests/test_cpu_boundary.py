@@ -304,7 +304,7 @@ def test_host_scalar_answers_host_reads_without_touching_the_tensor():
     """emap_amd.host_scalars.HostScalar (round 5): item / float / format / comparisons with python numbers / mean() of a constant tensor
     come from the host mirror (after waiting for ITS event only); every torch op still sees the tensor, and autograd stays attached."""
     import torch
-    from emap_amd.host_scalars import HostScalar
+    from emap_amd.host_scalars import HostScalar, _Slot
 
     class Ev:
         n = 0
@@ -315,15 +315,22 @@ def test_host_scalar_answers_host_reads_without_touching_the_tensor():
     host = torch.tensor([0.25, 7.5, 2.0, 0.0])
     p = torch.nn.Parameter(torch.tensor([0.5]))
     dev_val = (p * 0.5).expand(6, 1)                      # "variance": one number expanded over N*S rows, differentiable
-    v = HostScalar.wrap(dev_val, host, 0, Ev())
-    b = HostScalar.wrap(torch.tensor([7.5]), host, 1, Ev())
+    gen = [1]
+    v = HostScalar.wrap(dev_val, _Slot(host, Ev(), gen, 1, 3), 0)
+    b = HostScalar.wrap(torch.tensor([7.5]), _Slot(host, Ev(), gen, 1, 3), 1)
     assert isinstance(v, torch.Tensor) and v.shape == (6, 1)
     m = v.mean()
     assert isinstance(m, HostScalar) and m.dim() == 0 and m.item() == 0.25 and float(m) == 0.25
     c = m < 2 * b.item()
     assert isinstance(c, torch.Tensor) and c.device.type == "cpu" and bool(c) is True
     assert bool(m < 0.01) is False and bool(m >= 0.25) and "{:.2f}".format(m) == "0.25" and b.tolist() == [7.5]
-    assert Ev.n >= 5                                          # every host read waited for the mirror's event
+    assert Ev.n == 2                                          # the first host read of a push waited for ITS event and copied the values out
+    # the pinned buffer is a ring.  A push that was READ keeps its values after the buffer is reused ...
+    host[0], gen[0] = 99.0, 2
+    assert m.item() == 0.25 and v.mean().item() == 0.25
+    # ... one that was never read before the reuse falls back to the device tensor (never a later step's number)
+    late = HostScalar.wrap(torch.tensor([3.0]), _Slot(host, Ev(), gen, 1, 3), 0)
+    assert late.item() == 3.0 and float(late) == 3.0 and bool(late > 2.5)
     # torch ops: plain tensors out, values from the DEVICE tensor, autograd attached
     y = (v * 2.0).sum()
     assert type(y) is torch.Tensor

@@ -82,12 +82,10 @@ def _rank_step(rank, world, port, n_global, sync, q, backend="nccl", capture=Fal
     stats = step(batch, te, n_rays_global=n_global)
     torch.cuda.synchronize()
     r.check_errors()
-    if t._oneshot is not None:
-        t._oneshot.check()
+    t.check_errors()                 # renderer error word + the one-shot collective's time-out word
     q.put((rank, stats.cpu().numpy(), t.flat.data.cpu().numpy(), t.flat.grad[:t.flat.numel].cpu().numpy(), p0, stats1, grad1))
     if world > 1:
-        if t._oneshot is not None:
-            t._oneshot.close()
+        t.close()
         dist.barrier()
         dist.destroy_process_group()
 
@@ -320,6 +318,58 @@ def test_oneshot_allreduce_between_ranks_sharing_one_gpu(world):
         assert p.exitcode == 0
     for rank, ok, worst in res:
         assert ok and worst <= 1e-6, (rank, ok, worst)
+
+
+def _rank_oneshot_timeout(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    from emap_amd.parallel import OneShotAllReduce
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    n = 4096 + 3
+    ar = OneShotAllReduce(n, dev)
+    OneShotAllReduce.set_timeout_ms(100)                  # x6 for the region's first two launches
+    x = torch.ones(n, device=dev)
+    for _ in range(3):                                    # three healthy launches (past the start-up allowance)
+        y = ar(x.clone())
+    torch.cuda.synchronize()
+    ar.check()
+    healthy = bool((y == world).all())
+    dist.barrier()
+    raised, all_nan = False, None
+    if rank == 0:                                         # rank 1 never shows up for launch 4
+        y = ar(x.clone())
+        torch.cuda.synchronize()
+        all_nan = bool(torch.isnan(y).all())
+        try:
+            ar.check()
+        except RuntimeError:
+            raised = True
+    q.put((rank, healthy, all_nan, raised))
+    dist.barrier()
+    # no ar.close(): its barrier/unmap order is for healthy groups; the processes end here
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_oneshot_allreduce_timeout_is_loud():
+    """a peer that does not arrive within the time-out must not leave a partial sum in the bucket.  Rank 1 skips a
+    launch: rank 0's whole bucket is NaN (every consumer sees it) and check() raises; the launches before it were healthy."""
+    _need(1)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_oneshot_timeout, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict((r[0], r[1:]) for r in (q.get(timeout=300) for _ in range(2)))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res[0] == (True, True, True), res
+    assert res[1][0] is True
 
 
 @pytest.mark.timeout(900)
