@@ -357,17 +357,26 @@ class Trainer:
             # step's global maxima x 4 (the kernel rounds to a power of two) instead of waiting for a MAX all-reduce - or the rank's own
             # maxima where they exceed that, so that fp16 can never overflow: a rank whose gradients grew more than 4x in one step then
             # differs from the others in rounding for that step only.  The first step (no history) takes the exact path.
-            cur = self.r.bwd_absmax(S["call"])
-            tail = self._maxima_tail()
-            tail.zero_()
-            rank = dist.get_rank(self.group)
-            tail[2 * rank:2 * rank + 2] = cur
-            if self._lag_valid:
-                # scale = 4 x last step's GLOBAL maxima, clamped to [own maxima, 16 x own maxima]: the lower clamp keeps fp16 from
-                # overflowing when the gradients GREW more than 4 x in one step, the upper one from flushing small adjoints when they
-                # SHRANK more than 4 x (a stale scale 1000 x too large leaves fp16 three binades).  Inside the clamp every rank
-                # uses the same number; at a clamp the ranks differ in rounding for that step only.
-                cur.copy_(torch.minimum(torch.maximum(self._lag * 4.0, cur), cur * 16.0))
+            self._lag_publish(self.r.bwd_absmax(S["call"]), dist.get_rank(self.group))
+
+    def _lag_publish(self, cur: torch.Tensor, rank: int):
+        """exact_lagged, before the sweep: write this rank's two range maxima `cur` into ITS two slots of the bucket's tail (all other
+        slots zero: the bucket's SUM all-reduce is then an all-gather of them) and turn `cur` IN PLACE into the scale this step's sweep
+        uses - 4 x last step's GLOBAL maxima, clamped to [own maxima, 16 x own maxima]: the lower clamp keeps fp16 from overflowing
+        when the gradients GREW more than 4 x in one step, the upper one from flushing small adjoints when they SHRANK more than 4 x
+        (a stale scale 1000 x too large leaves fp16 three binades).  Inside the clamp every rank uses the same number; at a
+        clamp the ranks differ in rounding for that step only.  Without history (first step) `cur` is left alone."""
+        tail = self._maxima_tail()
+        tail.zero_()
+        tail[2 * rank:2 * rank + 2] = cur
+        if self._lag_valid:
+            cur.copy_(torch.minimum(torch.maximum(self._lag * 4.0, cur), cur * 16.0))
+
+    def _lag_collect(self):
+        """exact_lagged, after the bucket's all-reduce: the gathered per-rank maxima of THIS step become next step's global maxima."""
+        if self._lag_valid:
+            self._lag.copy_(self._maxima_tail().view(self.MAX_RANKS, 2).max(dim=0).values)
+        self._lag_valid = True
 
     def _maxima_tail(self):
         n = self.flat.numel + self.N_STATS
@@ -391,9 +400,7 @@ class Trainer:
         if S["world"] > 1 and self.eikonal_sync == "local":
             stats = self.flat.grad[self.flat.numel:self.flat.numel + 5]
         if S["lagged"]:
-            if self._lag_valid:      # the gathered per-rank maxima of THIS step -> next step's scale
-                self._lag.copy_(self._maxima_tail().view(self.MAX_RANKS, 2).max(dim=0).values)
-            self._lag_valid = True
+            self._lag_collect()
         self.optimizer.step()      # frozen scalars are skipped inside the kernel (device mask, refresh_trainable_mask)
         self.r.udf_network.invalidate_packed()   # the flat update does not bump the per-parameter version counters
         out = torch.empty(2, device=dev)         # a fresh tensor per step: callers keep what step() returned

@@ -189,3 +189,82 @@ def test_shard_and_flat_params_single_process():
     f.grad[:6] = 2.0
     assert torch.equal(ps[0].grad, torch.full((3, 2), 2.0)) and torch.equal(ps[1].grad, torch.zeros(5))
     assert f.span(ps) == (0, 11)
+
+
+# ---------------------------------------------------------------------------------------- exact_lagged's per-rank slots at world 8
+def _run_lagged_slots(rank, world, port, out_q):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    kw, net, dev, bet = _make()
+    tr = _oracle_trainer(kw, net, dev, bet, "exact_lagged")
+    assert tr.collectives_per_step == 2 and tr._maxima_tail().numel() == 2 * tr.MAX_RANKS
+    n = tr.flat.numel
+    # own range maxima of rank r at step s: a smooth history, then a 100x jump on rank 5 (step 3) and a 1000x collapse everywhere (step 4)
+    def own(r, s):
+        base = torch.tensor([1.0 + 0.25 * r, 0.5 + 0.125 * ((r * 3) % world)]) * (1.0 + 0.1 * s)
+        if s == 3 and r == 5:
+            base = base * 100.0
+        if s == 4:
+            base = base * 1e-3
+        return base
+    used, hist, sums = [], [], []
+    for s in range(5):
+        cur = own(rank, s).clone()
+        tr.flat.grad.zero_()
+        tr._lag_publish(cur, rank)                                  # slots <- own maxima; cur <- the scale this step's sweep would use
+        if not tr._lag_valid:                                       # first step: Trainer._collectives() runs the MAX all-reduce instead
+            dist.all_reduce(cur, op=dist.ReduceOp.MAX)
+            tr._lag.copy_(cur)
+        used.append(cur.clone())
+        tr.flat.grad[:n] = float(rank + 1) * (s + 1)                # "the gradients": the bucket's SUM must leave the slots intact
+        dist.all_reduce(tr.flat.grad, op=dist.ReduceOp.SUM)         # ONE collective: gradients + statistics + every rank's two maxima
+        sums.append(float(tr.flat.grad[0]))
+        tr._lag_collect()
+        hist.append(tr._lag.clone())
+    out_q.put((rank, torch.stack(used).numpy(), torch.stack(hist).numpy(), sums))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_exact_lagged_rank_slots_with_eight_ranks():
+    """the per-rank maxima slots in the gradient bucket's tail (Trainer._lag_publish / _lag_collect, the
+    eikonal_sync='exact_lagged' mode) had only ever run with 2 ranks.  8 gloo ranks, 5 steps with a 100x jump on one rank and a 1000x
+    collapse on all: every rank derives the same global history from the ONE bucket all-reduce, the scale it uses is
+    clamp(4 x previous global maxima, own, 16 x own), and the gradient part of the bucket is the plain sum."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_run_lagged_slots, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+
+    def own(r, s):
+        base = np.array([1.0 + 0.25 * r, 0.5 + 0.125 * ((r * 3) % world)], np.float32) * np.float32(1.0 + 0.1 * s)
+        if s == 3 and r == 5:
+            base = base * np.float32(100.0)
+        if s == 4:
+            base = base * np.float32(1e-3)
+        return base
+    glob = np.stack([np.max(np.stack([own(r, s) for r in range(world)]), axis=0) for s in range(5)])
+    for rank, used, hist, sums in res:
+        # step 0 seeds the history from the MAX all-reduce; from step 1 on the history is the max over the gathered slots of that step
+        assert np.allclose(hist[0], glob[0], rtol=1e-6)
+        for s in range(1, 5):
+            assert np.allclose(hist[s], glob[s], rtol=1e-6), (rank, s, hist[s], glob[s])
+            o = own(rank, s)
+            expect = np.minimum(np.maximum(4.0 * glob[s - 1], o), 16.0 * o)
+            assert np.allclose(used[s], expect, rtol=1e-6), (rank, s, used[s], expect)
+        # inside the clamp every rank uses the same number (step 1, 2); rank 5's own jump lifts only ITS scale at step 3
+        assert np.allclose(used[1], 4.0 * glob[0], rtol=1e-6) and np.allclose(used[2], 4.0 * glob[1], rtol=1e-6)
+        if rank == 5:
+            assert np.all(used[3] > 4.0 * glob[2])
+        assert np.all(used[4] <= 16.0 * own(rank, 4) * (1 + 1e-6))          # the collapse: capped at 16 x own, not 4 x a stale history
+        assert sums == [float(sum(range(1, world + 1)) * (s + 1)) for s in range(5)]
+    assert all(np.array_equal(res[0][2], r[2]) for r in res)                  # identical history on every rank
