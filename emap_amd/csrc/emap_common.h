@@ -164,7 +164,8 @@ struct IsLaunch {
 };
 constexpr int IS_NOT_FUSED = 1;
 int launch_importance(const NetLayout& L, const void* packed, int prec, const IsLaunch& q, hipStream_t st, int32_t* err_flags);
-int set_fused_sampling(int on);    // process-wide switch (tests, A/B): returns the previous value
+int set_fused_sampling(int on);    // process-wide switch (tests, A/B): 0 chain, 1 fused where the launcher's size rule picks it, 2 fused at every size; returns the previous value
+int fused_sampling_mode();
 int launch_mlp(const NetLayout& L, const void* packed, int prec, const PointSource& src, int64_t P,
                float* udf, float* grad3, hipStream_t st, int32_t* err_flags = nullptr, void* scratch = nullptr);
 int launch_null_direction(const float* g, int64_t n, int k, float* dir, hipStream_t st);

@@ -635,12 +635,13 @@ int launch_is_bf16x3(const NetLayout&, const void*, const IsLaunch&, hipStream_t
 int launch_is_f16(const NetLayout&, const void*, const IsLaunch&, hipStream_t, int32_t*);
 int launch_is_f16x3(const NetLayout&, const void*, const IsLaunch&, hipStream_t, int32_t*);
 
-static int fused_sampling_from_env() {      // EMAP_FUSED_SAMPLING=0: the launch chain (read ONCE at load, like EMAP_GRAD_MODE; at run time: emap_set_fused_sampling)
+static int fused_sampling_from_env() {      // EMAP_FUSED_SAMPLING=0: the launch chain; 2: fused whatever the launch size (A/B) (read ONCE at load, like EMAP_GRAD_MODE; at run time: emap_set_fused_sampling)
     const char* e = getenv("EMAP_FUSED_SAMPLING");
-    return (e && e[0] == '0') ? 0 : 1;
+    return (e && e[0] == '0') ? 0 : ((e && e[0] == '2') ? 2 : 1);
 }
 static std::atomic<int> g_fused_sampling{fused_sampling_from_env()};
-int set_fused_sampling(int on) { return g_fused_sampling.exchange(on ? 1 : 0, std::memory_order_relaxed); }
+int set_fused_sampling(int on) { return g_fused_sampling.exchange(on < 0 ? 0 : (on > 2 ? 2 : on), std::memory_order_relaxed); }
+int fused_sampling_mode() { return g_fused_sampling.load(std::memory_order_relaxed); }
 
 int launch_importance(const NetLayout& L, const void* packed, int prec, const IsLaunch& q, hipStream_t st, int32_t* err_flags) {
     if (!g_fused_sampling.load(std::memory_order_relaxed)) return IS_NOT_FUSED;

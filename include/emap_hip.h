@@ -192,9 +192,10 @@ int emap_composite_fwd_p(const float* rays_o, const float* rays_d, const float* 
                          const EmapRenderParams* p, const EmapCompositeOut* out, float* partials,
                          int32_t* err_flags, void* stream);
 
-/* ABI v8: emap_render_fwd runs importance_sample (udf_renderer_blending.py:802-841) as ONE launch where the shape allows (n_importance /
- * up_sample_steps == 16, fewer than 2048 rays); 0 restores the chain of 2 K - 1 launches (same results bit for bit: tests, A/B).
- * Process-wide; returns the previous value. */
+/* ABI v8: emap_render_fwd runs importance_sample (udf_renderer_blending.py:802-841) as ONE launch where the shape allows (ABI 9: 1 <=
+ * n_importance / up_sample_steps <= 16 new samples per step - the reference's default 50 / 5 = 10 included; launch-size rule in
+ * csrc/udf_mlp_kernel.inc:launch_is_mode); 0 restores the chain of 2 K - 1 launches (same results bit for bit: tests, A/B), 2 (ABI 9) uses
+ * the fused kernel at every launch size.  Process-wide; returns the previous value. */
 int emap_set_fused_sampling(int on);
 int emap_render_workspace_bytes(const EmapNetConfig* cfg, int prec, const EmapRenderParams* p, size_t* bytes);
 int emap_render_fwd(const EmapNetConfig* cfg, const void* packed, int prec, const EmapRenderParams* p,
