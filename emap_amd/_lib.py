@@ -80,6 +80,7 @@ SYMBOLS = {
     "emap_last_error": (C.c_char_p, []),
     "emap_set_grad_mode": (C.c_int, [C.c_int]),
     "emap_set_fused_sampling": (C.c_int, [C.c_int]),
+    "emap_set_fused_composite": (C.c_int, [C.c_int]),
     "emap_packed_bytes": (C.c_int, [C.POINTER(NetConfig), C.c_int, C.POINTER(C.c_size_t)]),
     "emap_pack_weights": (C.c_int, [C.POINTER(NetConfig), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), _P, C.c_int, _P]),
     "emap_udf_fwd": (C.c_int, [C.POINTER(NetConfig), _P, C.c_int, _P, C.c_int64, _P, _P]),

@@ -7,6 +7,8 @@
 #include <stdarg.h>
 #include <string.h>
 #include <algorithm>
+#include <atomic>
+#include <stdlib.h>
 
 namespace emap {
 
@@ -53,6 +55,10 @@ int launch_coarse(const float*, const float*, const float*, int, int, float*, fl
 int launch_composite(const float*, const float*, const float*, const float*, const float*, const float*, int, int,
                      const float*, float, float, float, float, int, float, float, float, float, int, const float*,
                      const float*, const float*, float, const EmapCompositeOut*, float*, int32_t*, hipStream_t);
+int fill_composite_args(const float*, const float*, const float*, const float*, const float*, const float*, int, int,
+                        const float*, float, float, float, float, int, float, float, float, float, int, const float*,
+                        const float*, const float*, float, const EmapCompositeOut*, float*, CompositeArgs*);
+int launch_composite_reduce(const CompositeArgs&, int32_t*, hipStream_t);
 int launch_embed(const float*, int64_t, int, float*, hipStream_t);
 void linspace_host(float, float, int, float*);
 int launch_sample_rays(const EmapRayDataset*, int, int, int, uint64_t, uint64_t, uint64_t*, const int64_t*, const EmapRayBatch*,
@@ -177,8 +183,16 @@ static int check_param_grads(const NetLayout& L, const EmapParamGrads* o, const 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Workspace {
-    size_t sample_dist, z_a, z_b, udf_a, udf_b, z_new, z_new2, udf_new, partials, rev, total;
+    size_t sample_dist, z_a, z_b, udf_a, udf_b, z_new, z_new2, udf_new, partials, ray_cnt, rev, total;
 };
+
+// render_core's tail inside the value + grad_x kernel (CompositeFuse; ABI 9).  EMAP_FUSED_COMPOSITE=0 / emap_set_fused_composite(0): the
+// separate composite_kernel launch of rounds 1-5 (same results bit for bit: tests, A/B).  Read once at load.
+static int fused_composite_from_env() {
+    const char* e = getenv("EMAP_FUSED_COMPOSITE");
+    return (e && e[0] == '0') ? 0 : 1;
+}
+static std::atomic<int> g_fused_composite{fused_composite_from_env()};
 
 static Workspace plan_workspace(const EmapRenderParams& p, const NetLayout* L = nullptr) {
     const size_t N = (size_t)std::max(p.n_rays, 0);
@@ -195,6 +209,7 @@ static Workspace plan_workspace(const EmapRenderParams& p, const NetLayout* L = 
     w.z_new2 = off; off += align256(N * (size_t)std::max(m, 1) * 4);
     w.udf_new = off; off += align256(N * (size_t)std::max(m, 1) * 4);
     w.partials = off; off += align256(N * 8 * 4);
+    w.ray_cnt = off; off += align256(N * 4);      // arrival counters of the fused compositing tail (int32 per ray)
     w.rev = off; off += L ? align256(rev_scratch_bytes(*L)) : 0;   // sigma' slabs of the reverse-mode value+gradient kernel
     w.total = off;
     return w;
@@ -208,6 +223,7 @@ extern "C" {
 
 int emap_abi_version(void) { return EMAP_ABI_VERSION; }
 int emap_set_fused_sampling(int on) { return set_fused_sampling(on); }
+int emap_set_fused_composite(int on) { return g_fused_composite.exchange(on ? 1 : 0, std::memory_order_relaxed); }
 const char* emap_last_error(void) { return g_err; }
 int emap_set_grad_mode(int mode) { return set_grad_mode(mode); }
 
@@ -358,11 +374,17 @@ int emap_render_fwd(const EmapNetConfig* cfg, const void* packed, int prec, cons
     float* znew[2] = {reinterpret_cast<float*>(ws + w.z_new), reinterpret_cast<float*>(ws + w.z_new2)};
     float* udf_new = reinterpret_cast<float*>(ws + w.udf_new);
     float* partials = reinterpret_cast<float*>(ws + w.partials);
+    // render_core's tail inside the final value + grad_x launch (ABI 9) where that launch is the reverse-sweep kernel: the first launch of
+    // the render clears the per-ray arrival counters, the final one composites every ray as its last tile completes
+    int32_t* ray_cnt = reinterpret_cast<int32_t*>(ws + w.ray_cnt);
+    const bool fuse_comp = g_fused_composite.load(std::memory_order_relaxed) && mlp_uses_rev(L, prec, (int64_t)N * S) &&
+                           comp_list_entries((int64_t)N * S, S) <= COMP_LIST_MAX;
 
     if (steps == 0) {
         // no up-sampling: the coarse samples (render() :700-720) are the final z_vals
         rc = launch_coarse(near, far, t_rand, N, Sc, z_vals, sample_dist, st);
         if (rc) return rc;
+        if (fuse_comp && hipMemsetAsync(ray_cnt, 0, (size_t)N * 4, st) != hipSuccess) { (void)hipGetLastError(); set_error("render_fwd: memset failed"); return EMAP_E_LAUNCH; }
     } else {
         // importance_sample (:802-841) in 2*steps launches: the coarse z_vals are evaluated where they are consumed (the first
         // MLP pass and the first sampler step, same separately rounded expression), every later sampler step merges the previous
@@ -371,9 +393,10 @@ int emap_render_fwd(const EmapNetConfig* cfg, const void* packed, int prec, cons
         memset(&src, 0, sizeof(src));
         src.rays_o = rays_o; src.rays_d = rays_d; src.n_per_ray = Sc; src.mid = 0; src.sample_dist = sample_dist;
         src.coarse = 1; src.near = near; src.far = far; src.t_rand = t_rand;
+        if (fuse_comp) { src.zero_cnt = ray_cnt; src.zero_n = N; }
         rc = launch_mlp(L, packed, prec, src, (int64_t)N * Sc, ubuf[0], nullptr, st, err_flags);
         if (rc) return rc;
-        src.coarse = 0;
+        src.coarse = 0; src.zero_cnt = nullptr; src.zero_n = 0;
         // everything from here to the final z_vals in ONE launch where the shape allows (16 new samples per ray and step, below 2048 rays):
         // sampler steps and MLP passes alternate inside the workgroup that owns the rays (udf_mlp_kernel.inc, IS)
         IsLaunch q;
@@ -414,11 +437,21 @@ int emap_render_fwd(const EmapNetConfig* cfg, const void* packed, int prec, cons
     PointSource fin;
     memset(&fin, 0, sizeof(fin));
     fin.rays_o = rays_o; fin.rays_d = rays_d; fin.z = z_vals; fin.n_per_ray = S; fin.mid = 1; fin.sample_dist = sample_dist;
+    CompositeFuse cf;
+    if (fuse_comp) {
+        rc = fill_composite_args(rays_o, rays_d, z_vals, udf, grad3, depth_scale, N, S, sample_dist, p->inv_s, p->beta, p->gamma,
+                                 p->cos_anneal_ratio, p->has_cos_anneal, p->flip_saturation, p->near_surface, p->sparse_scale,
+                                 p->background, p->has_background, p->variance_dev, p->beta_dev, p->gamma_dev, p->beta_min, out,
+                                 partials, &cf.c);
+        if (rc) return rc;
+        cf.ray_cnt = ray_cnt;
+    }
     {
         ProfScope ps(0, st);
-        rc = launch_mlp(L, packed, prec, fin, (int64_t)N * S, udf, grad3, st, err_flags, ws + w.rev);
+        rc = launch_mlp(L, packed, prec, fin, (int64_t)N * S, udf, grad3, st, err_flags, ws + w.rev, fuse_comp ? &cf : nullptr);
     }
     if (rc) return rc;
+    if (fuse_comp) return launch_composite_reduce(cf.c, err_flags, st);      // 4 launches per render: value pass, importance_sample, value + grad_x + compositing, reduction
     return launch_composite(rays_o, rays_d, z_vals, udf, grad3, depth_scale, N, S, sample_dist, p->inv_s, p->beta, p->gamma,
                             p->cos_anneal_ratio, p->has_cos_anneal, p->flip_saturation, p->near_surface, p->sparse_scale,
                             p->background, p->has_background, p->variance_dev, p->beta_dev, p->gamma_dev, p->beta_min, out,

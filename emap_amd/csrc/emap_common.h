@@ -132,9 +132,37 @@ struct PointSource {
     const float* far;
     const float* t_rand;       // may be null
     int32_t coarse;
-    int32_t pad;
+    int32_t zero_n;            // zero_cnt[0 .. zero_n) = 0 at the start of the launch (value passes: the per-ray arrival counters of the
+    int32_t* zero_cnt;         // render's fused compositing tail, CompositeFuse::ray_cnt); may be null
 };
 
+// ---- render_core's tail (udf_renderer_blending.py:435-455,463-677): arguments of composite_kernel / composite_ray (composite_dev.inc) ----
+struct CompositeArgs {
+    const float *rays_o, *rays_d, *z, *udf, *grad, *depth_scale, *sample_dist;
+    int N, S;
+    float inv_s, beta, gamma, car;
+    int anneal;
+    float flip_sat, near_surface, sparse_scale, background;
+    int has_bg;
+    const float *var_p, *beta_p, *gamma_p;  // optional raw device parameters (see EmapRenderParams)
+    float beta_min;
+    EmapCompositeOut out;
+    float* partials;
+};
+
+// What the fused tail of udf_mlp_rev32_kernel needs beside the compositing arguments: one arrival counter per ray (points of the ray
+// whose udf / grad_x have been written; zeroed by the first launch of the render, PointSource::zero_cnt).
+struct CompositeFuse {
+    CompositeArgs c;
+    int32_t* ray_cnt;
+};
+// upper bound on the rays ONE workgroup of the value + grad_x kernel can come to own (its list lives in the kernel's exchange buffer): every tile
+// it runs (64 points, <= 512 workgroups) can complete at most 64 / S + 2 rays
+constexpr int COMP_LIST_MAX = 8192;
+inline long long comp_list_entries(long long P, int S) {
+    const long long tiles = (P + 63) / 64, grid = tiles < 512 ? tiles : 512;
+    return ((tiles + grid - 1) / (grid > 0 ? grid : 1)) * (64 / (S > 0 ? S : 1) + 2);
+}
 // one fused step of importance_sample (sampler.hip:sampler_step_kernel)
 struct StepArgs {
     const float *rays_o, *rays_d;
@@ -166,8 +194,11 @@ constexpr int IS_NOT_FUSED = 1;
 int launch_importance(const NetLayout& L, const void* packed, int prec, const IsLaunch& q, hipStream_t st, int32_t* err_flags);
 int set_fused_sampling(int on);    // process-wide switch (tests, A/B): 0 chain, 1 fused where the launcher's size rule picks it, 2 fused at every size; returns the previous value
 int fused_sampling_mode();
+// fuse (value + grad_x launches that run the reverse-sweep kernel only - mlp_uses_rev()): the workgroup that writes the last point of a ray
+// composites that ray (BASELINE config C2: "fused MLP + composite"); the caller then launches only the cross-ray reduction.
 int launch_mlp(const NetLayout& L, const void* packed, int prec, const PointSource& src, int64_t P,
-               float* udf, float* grad3, hipStream_t st, int32_t* err_flags = nullptr, void* scratch = nullptr);
+               float* udf, float* grad3, hipStream_t st, int32_t* err_flags = nullptr, void* scratch = nullptr,
+               const CompositeFuse* fuse = nullptr);
 int launch_null_direction(const float* g, int64_t n, int k, float* dir, hipStream_t st);
 
 // ---- training backward (udf_mlp_vjp.inc, wgrad.hip) ---------------------------------------------------

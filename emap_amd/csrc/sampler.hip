@@ -185,122 +185,14 @@ __global__ __launch_bounds__(256) void coarse_z_kernel(const float* near, const 
 // ---------------------------------------------------------------------------------------------
 // render_core tail (udf_renderer_blending.py:435-455,463-677)
 // ---------------------------------------------------------------------------------------------
-struct CompositeArgs {
-    const float *rays_o, *rays_d, *z, *udf, *grad, *depth_scale, *sample_dist;
-    int N, S;
-    float inv_s, beta, gamma, car;
-    int anneal;
-    float flip_sat, near_surface, sparse_scale, background;
-    int has_bg;
-    const float *var_p, *beta_p, *gamma_p;  // optional raw device parameters (see EmapRenderParams)
-    float beta_min;
-    EmapCompositeOut out;
-    float* partials;
-};
+#include "composite_dev.inc"     // CompositeArgs + composite_ray<C, COH>: the per-ray body, shared with udf_mlp_rev32.inc's fused tail
 
 __device__ void composite_reduce_body(const float* partials, int N, float* scalars, int32_t* err, const CompositeArgs& a, int tid, int nthreads,
                                       double (*red)[5]);
 
-// Round 5: the ray lives in registers (lane l = samples [l C, (l+1) C), C = 1, 2 or 4), one burst of loads, neighbours over DPP, no LDS and
-// no barriers - see composite_bwd_kernel.  Same expressions and the same scan chunks as the LDS version of rounds 1-4.
 template <int C>
 __global__ __launch_bounds__(64) void composite_kernel(const CompositeArgs a) {
-    const int ray = blockIdx.x, lane = threadIdx.x, S = a.S;
-    const size_t rb = (size_t)ray * S;
-    float z[C + 1], u[C], gx[C], gy[C], gz[C], tc[C + 1];
-    bool ok[C], last[C];
-#pragma unroll
-    for (int i = 0; i < C; ++i) {
-        const int e = lane * C + i;
-        ok[i] = e < S; last[i] = !(e < S - 1);
-        const size_t q = rb + (ok[i] ? e : S - 1);
-        z[i] = a.z[q]; u[i] = a.udf[q];
-        gx[i] = a.grad[3 * q]; gy[i] = a.grad[3 * q + 1]; gz[i] = a.grad[3 * q + 2];
-    }
-    const float ox = a.rays_o[3 * ray], oy = a.rays_o[3 * ray + 1], oz = a.rays_o[3 * ray + 2];
-    const float dx = a.rays_d[3 * ray], dy = a.rays_d[3 * ray + 1], dz = a.rays_d[3 * ray + 2];
-    const float sd = *a.sample_dist;
-    float inv_s_ = a.inv_s, beta_ = a.beta, gamma_ = a.gamma;
-    if (a.var_p) {  // udf_model.py:226-227,259-263 + udf_renderer_blending.py:466-472
-        inv_s_ = clipf(expf(FMUL(a.var_p[0], 10.0f)), 1e-6f, 1e6f);
-        beta_ = clipf(clipf(expf(FMUL(a.beta_p[0], 10.0f)), 0.0f, FDIV(1.0f, a.beta_min)), 1e-6f, 1e6f);
-        gamma_ = clipf(expf(FMUL(a.gamma_p[0], 10.0f)), 1e-6f, 1e6f);
-    }
-#pragma unroll
-    for (int i = 0; i < C; ++i) tc[i] = FADD(FADD(FMUL(dx, gx[i]), FMUL(dy, gy[i])), FMUL(dz, gz[i]));      // :482
-    z[C] = dpp_next_f(0.f, z[0]);       // sample e+1 of a lane's last sample is the next lane's first
-    tc[C] = dpp_next_f(0.f, tc[0]);
-    float dists[C], av[C], sb[C];
-#pragma unroll
-    for (int i = 0; i < C; ++i) {
-        dists[i] = last[i] ? sd : FSUB(z[i + 1], z[i]);                                 // :435-444
-        const float raw_occ = udf2logistic1(u[i], beta_);                               // :492
-        const float occ = FSUB(1.0f, expf(FMUL(FMUL(-relu_(raw_occ), gamma_), dists[i])));   // :497
-        const float vis_mask = last[i] ? 1.0f : ((tc[i + 1] < 0.01f) ? 1.0f : 0.0f);    // :500-509
-        av[i] = FADD(clipf(FADD(FSUB(1.0f, occ), FMUL(a.flip_sat, vis_mask)), 0.0f, 1.0f), 1e-7f);  // :515
-    }
-    ray_prefix_prod<C>(av, ok, sb);     // vis_prob (:511-523)
-    float alpha[C];
-#pragma unroll
-    for (int i = 0; i < C; ++i) {
-        const float vp = clipf(sb[i], 0.0f, 1.0f);                                      // :528
-        const float tcn = -fabsf(tc[i]);
-        const float ap = sdf2alpha(u[i], tcn, dists[i], inv_s_, a.anneal != 0, a.car);  // :530-543
-        const float am = sdf2alpha(-u[i], tcn, dists[i], inv_s_, a.anneal != 0, a.car);
-        alpha[i] = FADD(FMUL(ap, vp), FMUL(am, FSUB(1.0f, vp)));                        // :545
-        av[i] = FADD(FSUB(1.0f, alpha[i]), 1e-7f);
-    }
-    ray_prefix_prod<C>(av, ok, sb);     // transmittance (:593-602)
-    double wsum = 0, dsum = 0, nx = 0, ny = 0, nz = 0, e_rel = 0, c_rel = 0, e_ns = 0, c_ns = 0, sp = 0;
-#pragma unroll
-    for (int i = 0; i < C; ++i) {
-        const float w = FMUL(alpha[i], sb[i]);
-        const float mid = FADD(z[i], FMUL(dists[i], 0.5f));                             // :446
-        const float px = FADD(ox, FMUL(dx, mid)), py = FADD(oy, FMUL(dy, mid)), pz = FADD(oz, FMUL(dz, mid));
-        const float pn = sqrtf(FADD(FADD(FMUL(px, px), FMUL(py, py)), FMUL(pz, pz)));   // :563
-        const float gm = sqrtf(FADD(FADD(FMUL(gx[i], gx[i]), FMUL(gy[i], gy[i])), FMUL(gz[i], gz[i])));   // :463
-        const float gi = FADD(gm, 1e-5f);
-        const float cosn = FADD(FADD(FMUL(dx, FDIV(gx[i], gi)), FMUL(dy, FDIV(gy[i], gi))), FMUL(dz, FDIV(gz[i], gi)));  // :485
-        const float flip = (cosn > 0.f) ? -1.0f : 1.0f;                                 // :486-489
-        const float inside = (pn < 2.0f) ? 1.0f : 0.0f, relax = (pn < 2.4f) ? 1.0f : 0.0f;  // :568-569
-        const float ns = (u[i] < a.near_surface) ? 1.0f : 0.0f;                         // :570
-        const float ge = FMUL(FSUB(gm, 1.0f), FSUB(gm, 1.0f));                          // :612-617
-        if (ok[i]) {
-            const size_t q = rb + lane * C + i;
-            if (a.out.weights) a.out.weights[q] = w;
-            if (a.out.alpha) a.out.alpha[q] = alpha[i];
-            if (a.out.mid_z) a.out.mid_z[q] = mid;
-            if (a.out.dists) a.out.dists[q] = dists[i];
-            if (a.out.inside_sphere) a.out.inside_sphere[q] = inside;
-            if (a.out.gradient_mag) a.out.gradient_mag[q] = gm;
-            if (a.out.gradients_flip) {
-                a.out.gradients_flip[3 * q] = FMUL(flip, gx[i]);
-                a.out.gradients_flip[3 * q + 1] = FMUL(flip, gy[i]);
-                a.out.gradients_flip[3 * q + 2] = FMUL(flip, gz[i]);
-            }
-            wsum += w;
-            dsum += (double)FMUL(mid, w);
-            nx += (double)FMUL(FMUL(flip, gx[i]), w); ny += (double)FMUL(FMUL(flip, gy[i]), w); nz += (double)FMUL(FMUL(flip, gz[i]), w);
-            e_rel += (double)FMUL(relax, ge); c_rel += relax;
-            e_ns += (double)FMUL(ns, ge); c_ns += ns;
-            sp += (double)expf(FMUL(-a.sparse_scale, u[i]));                            // :642-644
-        }
-    }
-    wsum = wave_sum_d(wsum); dsum = wave_sum_d(dsum);
-    nx = wave_sum_d(nx); ny = wave_sum_d(ny); nz = wave_sum_d(nz);
-    e_rel = wave_sum_d(e_rel); c_rel = wave_sum_d(c_rel); e_ns = wave_sum_d(e_ns); c_ns = wave_sum_d(c_ns);
-    sp = wave_sum_d(sp);
-    if (lane == 0) {
-        const float ws = (float)wsum;
-        float edge = ws;                                                                 // :606 (sampled_edge == 1)
-        if (a.has_bg) edge = FADD(edge, FMUL(a.background, FSUB(1.0f, ws)));             // :608-609
-        if (a.out.edge) a.out.edge[ray] = edge;
-        if (a.out.weight_sum) a.out.weight_sum[ray] = ws;
-        if (a.out.depth) a.out.depth[ray] = a.depth_scale ? FMUL((float)dsum, a.depth_scale[ray]) : (float)dsum;  // :607, render :786
-        if (a.out.normals) { a.out.normals[3 * ray] = (float)nx; a.out.normals[3 * ray + 1] = (float)ny; a.out.normals[3 * ray + 2] = (float)nz; }
-        float* p = a.partials + (size_t)ray * 8;
-        p[0] = (float)e_rel; p[1] = (float)c_rel; p[2] = (float)e_ns; p[3] = (float)c_ns; p[4] = (float)sp;
-    }
+    composite_ray<C, false>(a, blockIdx.x, threadIdx.x);
 }
 
 // deterministic cross-ray reduction of the eikonal terms (:618-625) and sparse_error (:642-644)
@@ -681,21 +573,39 @@ int launch_coarse(const float* near, const float* far, const float* t_rand, int 
     return check_launch("coarse_z");
 }
 
-int launch_composite(const float* rays_o, const float* rays_d, const float* z, const float* udf, const float* grad3,
-                     const float* depth_scale, int N, int S, const float* sample_dist, float inv_s, float beta,
-                     float gamma, float car, int anneal, float flip_sat, float near_surface, float sparse_scale,
-                     float background, int has_bg, const float* var_p, const float* beta_p, const float* gamma_p,
-                     float beta_min, const EmapCompositeOut* out, float* partials, int32_t* err, hipStream_t st) {
+int fill_composite_args(const float* rays_o, const float* rays_d, const float* z, const float* udf, const float* grad3,
+                        const float* depth_scale, int N, int S, const float* sample_dist, float inv_s, float beta,
+                        float gamma, float car, int anneal, float flip_sat, float near_surface, float sparse_scale,
+                        float background, int has_bg, const float* var_p, const float* beta_p, const float* gamma_p,
+                        float beta_min, const EmapCompositeOut* out, float* partials, CompositeArgs* pa) {
     if (S < 1 || S > MAXS) { set_error("composite: S=%d out of range (max %d)", S, MAXS); return EMAP_E_INVALID; }
     if (!out || !partials) { set_error("composite: out/partials must not be null"); return EMAP_E_INVALID; }
-    if (N <= 0) return EMAP_OK;
-    CompositeArgs a;
+    if (var_p && (!beta_p || !gamma_p)) { set_error("composite: variance_dev given without beta_dev/gamma_dev"); return EMAP_E_INVALID; }
+    CompositeArgs& a = *pa;
     a.rays_o = rays_o; a.rays_d = rays_d; a.z = z; a.udf = udf; a.grad = grad3; a.depth_scale = depth_scale;
     a.sample_dist = sample_dist; a.N = N; a.S = S; a.inv_s = inv_s; a.beta = beta; a.gamma = gamma; a.car = car;
     a.anneal = anneal; a.flip_sat = flip_sat; a.near_surface = near_surface; a.sparse_scale = sparse_scale;
     a.background = background; a.has_bg = has_bg; a.out = *out; a.partials = partials;
     a.var_p = var_p; a.beta_p = beta_p; a.gamma_p = gamma_p; a.beta_min = beta_min;
-    if (var_p && (!beta_p || !gamma_p)) { set_error("composite: variance_dev given without beta_dev/gamma_dev"); return EMAP_E_INVALID; }
+    return EMAP_OK;
+}
+
+// the deterministic cross-ray reduction alone: what is left to launch when the value + grad_x kernel composited the rays itself (CompositeFuse)
+int launch_composite_reduce(const CompositeArgs& a, int32_t* err, hipStream_t st) {
+    if (a.N > 0 && a.out.scalars) hipLaunchKernelGGL(composite_reduce_kernel, dim3(1), dim3(256), 0, st, a.partials, a.N, a.out.scalars, err, a);
+    return check_launch("composite_reduce");
+}
+
+int launch_composite(const float* rays_o, const float* rays_d, const float* z, const float* udf, const float* grad3,
+                     const float* depth_scale, int N, int S, const float* sample_dist, float inv_s, float beta,
+                     float gamma, float car, int anneal, float flip_sat, float near_surface, float sparse_scale,
+                     float background, int has_bg, const float* var_p, const float* beta_p, const float* gamma_p,
+                     float beta_min, const EmapCompositeOut* out, float* partials, int32_t* err, hipStream_t st) {
+    CompositeArgs a;
+    const int rc = fill_composite_args(rays_o, rays_d, z, udf, grad3, depth_scale, N, S, sample_dist, inv_s, beta, gamma, car, anneal, flip_sat,
+                                       near_surface, sparse_scale, background, has_bg, var_p, beta_p, gamma_p, beta_min, out, partials, &a);
+    if (rc) return rc;
+    if (N <= 0) return EMAP_OK;
     if (S <= 64) hipLaunchKernelGGL(composite_kernel<1>, dim3(N), dim3(64), 0, st, a);
     else if (S <= 128) hipLaunchKernelGGL(composite_kernel<2>, dim3(N), dim3(64), 0, st, a);
     else hipLaunchKernelGGL(composite_kernel<4>, dim3(N), dim3(64), 0, st, a);

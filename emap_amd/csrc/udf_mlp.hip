@@ -588,10 +588,10 @@ int launch_pack(const NetLayout& L, const float* const* g, const float* const* v
     return check_launch("pack_weights");
 }
 
-int launch_mlp_bf16(const NetLayout&, const void*, const PointSource&, int64_t, float*, float*, hipStream_t, int, int32_t*, void*);
-int launch_mlp_bf16x3(const NetLayout&, const void*, const PointSource&, int64_t, float*, float*, hipStream_t, int, int32_t*, void*);
-int launch_mlp_f16(const NetLayout&, const void*, const PointSource&, int64_t, float*, float*, hipStream_t, int, int32_t*, void*);
-int launch_mlp_f16x3(const NetLayout&, const void*, const PointSource&, int64_t, float*, float*, hipStream_t, int, int32_t*, void*);
+int launch_mlp_bf16(const NetLayout&, const void*, const PointSource&, int64_t, float*, float*, hipStream_t, int, int32_t*, void*, const CompositeFuse*);
+int launch_mlp_bf16x3(const NetLayout&, const void*, const PointSource&, int64_t, float*, float*, hipStream_t, int, int32_t*, void*, const CompositeFuse*);
+int launch_mlp_f16(const NetLayout&, const void*, const PointSource&, int64_t, float*, float*, hipStream_t, int, int32_t*, void*, const CompositeFuse*);
+int launch_mlp_f16x3(const NetLayout&, const void*, const PointSource&, int64_t, float*, float*, hipStream_t, int, int32_t*, void*, const CompositeFuse*);
 
 // kernel variant: 2 = "fs2" (udf_mlp_fs2_kernel: every value launch, forward-mode tangents for small grad launches),
 // 3 = "rev" (grad launches only: forward + reverse sweep on 32x32 MFMA tiles, udf_mlp_rev32.inc).
@@ -616,15 +616,16 @@ static int mlp_variant(const NetLayout& L, int prec, int64_t P, bool grad) {
 bool mlp_uses_rev(const NetLayout& L, int prec, int64_t P) { return mlp_variant(L, prec, P, true) == 3; }
 
 int launch_mlp(const NetLayout& L, const void* packed, int prec, const PointSource& src, int64_t P, float* udf,
-               float* grad3, hipStream_t st, int32_t* err_flags, void* scratch) {
+               float* grad3, hipStream_t st, int32_t* err_flags, void* scratch, const CompositeFuse* fuse) {
     const int v = mlp_variant(L, prec, P, grad3 != nullptr);
+    if (fuse && v != 3) { set_error("launch_mlp: the fused compositing tail needs the reverse-sweep kernel (mlp_uses_rev)"); return EMAP_E_INVALID; }
     switch (prec) {
-        case EMAP_PREC_BF16: return launch_mlp_bf16(L, packed, src, P, udf, grad3, st, v, err_flags, scratch);
-        case EMAP_PREC_BF16X3: return launch_mlp_bf16x3(L, packed, src, P, udf, grad3, st, v, err_flags, scratch);
-        case EMAP_PREC_F16: return launch_mlp_f16(L, packed, src, P, udf, grad3, st, v, err_flags, scratch);
+        case EMAP_PREC_BF16: return launch_mlp_bf16(L, packed, src, P, udf, grad3, st, v, err_flags, scratch, fuse);
+        case EMAP_PREC_BF16X3: return launch_mlp_bf16x3(L, packed, src, P, udf, grad3, st, v, err_flags, scratch, fuse);
+        case EMAP_PREC_F16: return launch_mlp_f16(L, packed, src, P, udf, grad3, st, v, err_flags, scratch, fuse);
         case EMAP_PREC_F16X3:
         case EMAP_PREC_F16X3E:
-        case EMAP_PREC_F16X3M: return launch_mlp_f16x3(L, packed, src, P, udf, grad3, st, v, err_flags, scratch);   // L.mx_fwd selects the kernel
+        case EMAP_PREC_F16X3M: return launch_mlp_f16x3(L, packed, src, P, udf, grad3, st, v, err_flags, scratch, fuse);   // L.mx_fwd selects the kernel
     }
     set_error("unknown precision mode %d", prec);
     return EMAP_E_INVALID;

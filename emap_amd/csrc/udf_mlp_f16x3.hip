@@ -2,8 +2,8 @@
 #include "udf_mlp_kernel.inc"
 namespace emap {
 int launch_mlp_f16x3(const NetLayout& L, const void* packed, const PointSource& src, int64_t P, float* udf, float* grad3,
-                      hipStream_t st, int variant, int32_t* err, void* scratch) {
-    if (variant == 3) return launch_mlp_rev32_mode<EMAP_PREC_F16X3>(L, packed, src, P, udf, grad3, st, err, scratch);
+                      hipStream_t st, int variant, int32_t* err, void* scratch, const CompositeFuse* fuse) {
+    if (variant == 3) return launch_mlp_rev32_mode<EMAP_PREC_F16X3>(L, packed, src, P, udf, grad3, st, err, scratch, fuse);
     return launch_mlp_fs2_mode<EMAP_PREC_F16X3>(L, packed, src, P, udf, grad3, st, err);
 }
 int launch_vjp_sweep_f16x3(const NetLayout& L, const void* packed, const PointSource& src, int64_t P, int tile0, int n_tiles,

@@ -197,6 +197,12 @@ int emap_composite_fwd_p(const float* rays_o, const float* rays_d, const float* 
  * csrc/udf_mlp_kernel.inc:launch_is_mode); 0 restores the chain of 2 K - 1 launches (same results bit for bit: tests, A/B), 2 (ABI 9) uses
  * the fused kernel at every launch size.  Process-wide; returns the previous value. */
 int emap_set_fused_sampling(int on);
+/* ABI v9: emap_render_fwd composites every ray INSIDE the final value + grad_x launch (the workgroup that writes a ray's last point runs
+ * render_core's tail for it, udf_renderer_blending.py:463-625; BASELINE config C2: "fused MLP + composite kernel") whenever that launch is
+ * the reverse-sweep kernel (>= 10 240 points in the split modes); only the deterministic cross-ray reduction stays a launch of its own.
+ * 0 restores the separate compositing launch (same results bit for bit: tests, A/B; EMAP_FUSED_COMPOSITE=0 at load).  Process-wide;
+ * returns the previous value. */
+int emap_set_fused_composite(int on);
 int emap_render_workspace_bytes(const EmapNetConfig* cfg, int prec, const EmapRenderParams* p, size_t* bytes);
 int emap_render_fwd(const EmapNetConfig* cfg, const void* packed, int prec, const EmapRenderParams* p,
                     const float* rays_o, const float* rays_d, const float* near, const float* far,

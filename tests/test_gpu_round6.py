@@ -101,3 +101,113 @@ def test_fused_importance_sampling_at_2048_rays_and_more(N, ns, ni, K):
 @pytest.mark.parametrize("prec", ["f16x3m", "f16x3e", "bf16x3", "bf16"])
 def test_fused_importance_sampling_m10_in_other_precision_modes(prec):
     _fused_vs_chain("d8w256L10", 512, prec, 64, 50, 5)
+
+
+# ------------------------------------------------------------------------------------------------ compositing inside the value + grad_x kernel
+def _render_both_ways(r, args, kw, reduced=False):
+    L = _lib.lib()
+    outs = {}
+    try:
+        for fused in (1, 0):
+            L.emap_set_fused_composite(fused)
+            with torch.no_grad():
+                o = (r.render_reduced if reduced else r.render)(*args, **kw)
+            torch.cuda.synchronize()
+            r.check_errors()
+            outs[fused] = {k: v.clone() for k, v in o.items() if isinstance(v, torch.Tensor)}
+    finally:
+        L.emap_set_fused_composite(1)
+    return outs
+
+
+@pytest.mark.parametrize("netname,N,ns,ni,K", [
+    ("d8w256L10", 512, 64, 64, 4),       # the benchmark batch: a ray = two 64-point tiles, written by two workgroups
+    ("d8w256L10", 1024, 64, 50, 5),      # 114 samples per ray: tiles straddle rays
+    ("d8w256L10", 100, 64, 64, 4), ("d8w256L10", 333, 32, 32, 4), ("d8w256L10", 1500, 64, 64, 4),
+    ("d8w256L10", 700, 16, 16, 2),       # 32 samples per ray: two rays per tile
+    ("d8w256L10", 90, 64, 192, 4),       # 256 samples per ray (C = 4)
+    ("d8w256L10", 4096, 64, 64, 4),      # four rounds of workgroups
+    ("d4w128L10", 512, 64, 64, 4), ("d4w128L10", 400, 32, 30, 3),
+])
+def test_fused_compositing_equals_the_separate_launch_bit_for_bit(netname, N, ns, ni, K):
+    """ABI 9 / BASELINE config C2 ("fused MLP + composite kernel"): render_core's tail (udf_renderer_blending.py:463-625) runs inside
+    udf_mlp_rev32_kernel<..., COMP> - the workgroup that completes a ray composites it - against the separate composite_kernel launch
+    (emap_set_fused_composite(0)): every entry of the render dict identical bit for bit, also when tiles straddle rays, when a tile holds
+    several rays, and over several rounds of workgroups."""
+    from test_gpu_parity import mk, mk_renderer
+    net, _, _ = mk(netname, "f16x3")
+    r = mk_renderer(net, ns, ni, K)
+    ro, rd, near, far, ds = [v.to(DEV) for v in synthetic.make_rays(N, seed=9)]
+    tr = synthetic.make_t_rand(N).to(DEV)
+    assert N * (ns + ni) >= 10240                                  # the reverse-sweep kernel (the only one with the fused tail) runs
+    kw = dict(cos_anneal_ratio=0.7, flip_saturation=0.9, t_rand=tr)
+    outs = _render_both_ways(r, (ro, rd, near, far, ds), kw)
+    assert set(outs[0]) == set(outs[1]) and {"edge", "weights", "gradient_error", "normals", "depth"} <= set(outs[1])
+    for k in outs[1]:
+        assert torch.equal(outs[1][k], outs[0][k]), k
+    red = _render_both_ways(r, (ro, rd, near, far, ds), kw, reduced=True)
+    for k in red[1]:
+        assert torch.equal(red[1][k], red[0][k]), k
+    assert torch.equal(red[1]["edge"], outs[1]["edge"])
+
+
+@pytest.mark.parametrize("prec", ["f16x3e", "f16x3m", "bf16x3", "f16", "bf16"])
+def test_fused_compositing_in_every_precision_mode(prec):
+    from test_gpu_parity import mk, mk_renderer
+    net, _, _ = mk("d8w256L10", prec)
+    r = mk_renderer(net, 64, 64, 4)
+    N = 512
+    ro, rd, near, far, ds = [v.to(DEV) for v in synthetic.make_rays(N, seed=3)]
+    outs = _render_both_ways(r, (ro, rd, near, far, ds), dict(cos_anneal_ratio=1.0, flip_saturation=0.9, perturb_overwrite=0))
+    for k in outs[1]:
+        assert torch.equal(outs[1][k], outs[0][k]), (prec, k)
+
+
+def test_fused_compositing_from_a_replayed_graph_and_back_to_back():
+    """The arrival counters are cleared by the render's FIRST launch: 40 replays of a captured render and 40 eager renders back to back
+    (no synchronisation between them) give the same dict every time."""
+    from test_gpu_parity import mk, mk_renderer
+    net, _, _ = mk("d8w256L10", "f16x3")
+    r = mk_renderer(net, 64, 64, 4)
+    N = 512
+    ro, rd, near, far, ds = [v.to(DEV) for v in synthetic.make_rays(N, seed=4)]
+    tr = synthetic.make_t_rand(N).to(DEV)
+    kw = dict(cos_anneal_ratio=1.0, flip_saturation=0.9, t_rand=tr)
+    ref = _render_both_ways(r, (ro, rd, near, far, ds), kw)[0]
+    g = r.capture(ro, rd, near, far, ds, **kw)
+    for i in range(40):
+        o = g()
+        if i % 13 == 0 or i == 39:
+            for k in ("edge", "weights", "depth", "normals", "gradient_error"):
+                assert torch.equal(o[k], ref[k]), (i, k)
+    keep = []
+    with torch.no_grad():
+        for i in range(40):
+            keep.append(r.render(ro, rd, near, far, ds, **kw))
+    torch.cuda.synchronize()
+    for o in keep[::7] + keep[-1:]:
+        for k in ("edge", "weights", "depth", "normals", "gradient_error"):
+            assert torch.equal(o[k], ref[k]), k
+
+
+def test_training_forward_uses_the_fused_tail_and_the_gradients_do_not_change():
+    from test_gpu_parity import mk, mk_renderer
+    L = _lib.lib()
+    res = {}
+    try:
+        for fused in (1, 0):
+            L.emap_set_fused_composite(fused)
+            net, _, _ = mk("d8w256L10", "f16x3")
+            r = mk_renderer(net, 64, 64, 4)
+            N = 256
+            ro, rd, near, far, ds = [v.to(DEV) for v in synthetic.make_rays(N, seed=6)]
+            te = synthetic.make_true_edge(N, seed=7).to(DEV)
+            out = r.render(ro, rd, near, far, ds, cos_anneal_ratio=1.0, perturb_overwrite=0, flip_saturation=0.9)
+            loss = emap_amd.EdgeLoss("mse")(out["edge"], te) + 0.1 * out["gradient_error"]
+            loss.backward()
+            torch.cuda.synchronize()
+            r.check_errors()
+            res[fused] = (float(loss), torch.cat([p.grad.reshape(-1) for p in net.parameters()]).clone())
+    finally:
+        L.emap_set_fused_composite(1)
+    assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1])
