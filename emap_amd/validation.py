@@ -2,8 +2,10 @@
 
 The reference splits the H*W rays of an image into ``batch_size`` chunks, calls ``renderer.render`` per chunk and copies
 ``edge``, ``depth`` and the weighted normal ``sum_s gradients_flip * weights`` of every chunk to the host (three
-``.detach().cpu().numpy()`` round trips per chunk).  Here the same quantities are produced by launches of ``launch_rays`` rays
-(default 8192: every MLP pass fills the chip) in the renderer's REDUCED output mode - the compositing kernel is handed NULL
+``.detach().cpu().numpy()`` round trips per chunk).  Here the same quantities are produced by ONE ``emap_render_fwd`` call over all
+H*W rays (round 6; ``launch_rays=None``: up to 2**18 rays per call - every kernel of the path strides over its ray / point tiles
+with a resident grid, so a 400 x 400 image is one chain of 10 launches instead of 20 chains of 5; rounds 1-5: 8192 rays per call)
+in the renderer's REDUCED output mode - the compositing kernel is handed NULL
 for every per-sample output and writes only edge, depth, the weighted normal and weight_sum: 28 B per ray instead of the
 48 B per sample of the training dict - stay on the device and are copied to the host once.  The per-chunk jitter
 draws of the reference (``torch.rand([chunk, 1])`` on the CPU generator, udf_renderer_blending.py:719) are reproduced in the
@@ -15,13 +17,15 @@ import torch
 
 
 def render_image(renderer, rays_o, rays_d, near, far, depth_scale, batch_size, cos_anneal_ratio=None, background_rgb=None,
-                 launch_rays=8192, to_numpy=True):
+                 launch_rays=None, to_numpy=True):
     """rays_o, rays_d (H,W,3) or (n,3); depth_scale (H,W,1) or (n,1).  Returns {"edge": (n,1), "depth": (n,1),
     "normals": (n,3)} as numpy arrays (the lists ``out_edge_fine / out_depth / out_normal_fine`` of the reference, concatenated)."""
     ro = rays_o.reshape(-1, 3)
     rd = rays_d.reshape(-1, 3)
     ds = depth_scale.reshape(-1, 1)
     n = ro.shape[0]
+    if launch_rays is None:
+        launch_rays = 1 << 18      # one call for any image up to 512 x 512; the workspace of a call is ~2 KiB per ray
     # jitter: one draw per reference chunk, in the reference's order (render() :718-720 with perturb_overwrite = -1)
     t_rand = None
     if renderer.perturb > 0:

@@ -211,3 +211,30 @@ def test_training_forward_uses_the_fused_tail_and_the_gradients_do_not_change():
     finally:
         L.emap_set_fused_composite(1)
     assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1])
+
+
+# ------------------------------------------------------------------------------------------------ full image in one call (SURVEY par. 8 f4)
+def test_whole_image_in_one_call_equals_the_chunked_schedules():
+    """render_image's default (round 6): ONE emap_render_fwd call over all H*W rays (runner_udf.py:298-327 loops over batch_size chunks).
+    Rays are independent: the same image as 1024-ray launches bit for bit (the same kernels run at both sizes: >= 10 240 points), and as
+    the reference's 512-ray schedule to the render tolerances."""
+    from test_gpu_parity import mk, mk_renderer, rel, t
+    from emap_amd.validation import render_image
+    net, _, _ = mk("d8w256L10", "f16x3")
+    r = mk_renderer(net, 64, 64, 4)
+    H, W = 96, 100                       # 9600 rays: the sampler's launch chain (>= 2048 rays) and several rounds of every grid
+    ro, rd, near, far, ds = synthetic.make_rays(H * W, seed=13)
+    ro, rd, ds = ro.to(DEV), rd.to(DEV), ds.to(DEV)
+    nf, ff = float(near.reshape(-1)[0]), float(far.reshape(-1)[0])
+    r.perturb = 1.0
+    imgs = {}
+    for lr in (None, 4096, 512):
+        torch.manual_seed(5)
+        imgs[lr] = render_image(r, ro.reshape(H, W, 3), rd.reshape(H, W, 3), nf, ff, ds.reshape(H, W, 1), batch_size=512,
+                                cos_anneal_ratio=1.0, launch_rays=lr, to_numpy=False)
+    torch.cuda.synchronize()
+    r.check_errors()
+    for k in ("edge", "depth", "normals"):
+        assert imgs[None][k].shape[0] == H * W
+        assert torch.equal(imgs[None][k], imgs[4096][k]), k
+        assert rel(imgs[None][k], imgs[512][k]) <= 5e-4, k
