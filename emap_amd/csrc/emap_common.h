@@ -240,9 +240,12 @@ extern int g_prof_clk_device;
 long long* prof_clk_here();   // g_prof_clk if the current device is the one it was allocated on, else null
 extern long long* g_prof_clk;   // device buffer of 8 x int64 while emap_profile_enable(1) is in effect, else null (clock_stamp in udf_mlp_kernel.inc)
 constexpr int REV_MAX_WG = 768;      // persistent workgroups of the reverse-mode kernel (3 per CU)
-inline size_t rev_scratch_bytes(const NetLayout& L) {   // sigmoid stash: [workgroup][layer][pair][4][64 lanes x 16 B]
+// sigma' stash of the reverse-mode kernel per row tile and column tile of 32 points: 16 values per lane x 64 lanes, 3 bytes reserved per value
+// (unorm16 planes; precision mode f16x3e adds one plane of low bytes - udf_mlp_rev32.inc, SG24)
+constexpr int REV_SG_BYTES_PER_NC = 3072;
+inline size_t rev_scratch_bytes(const NetLayout& L) {   // sigmoid stash: [workgroup][layer][pair][6][64 lanes x 16 B]
     // + 8 KiB per workgroup: the lo parts of the tile's PE block (MX6F: their LDS slots hold the fp6 forms; read back by the PE rows)
-    return L.has_rev ? (size_t)(REV_MAX_WG * 2 / 3) * ((size_t)(L.n_lin - 1) * (size_t)(L.H / 32) * 4096 + 8192) : 0;   // 2 resident workgroups per CU
+    return L.has_rev ? (size_t)(REV_MAX_WG * 2 / 3) * ((size_t)(L.n_lin - 1) * (size_t)(L.H / 32) * (2 * REV_SG_BYTES_PER_NC) + 8192) : 0;   // 2 resident workgroups per CU
 }
 
 }  // namespace emap

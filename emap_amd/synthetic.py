@@ -194,3 +194,40 @@ def make_wireframe_scene(n_images: int = 16, H: int = 200, W: int = 200, radius:
     meta = {"scene_box": {"near": 0.05, "far": 6.0, "radius": 1.0, "aabb": [[-1, -1, -1], [1, 1, 1]]}, "height": H, "width": W,
             "frames": frames}
     return meta, edges
+
+
+def scene_rays(meta, edges, img_idx: int, px, py, dtype=torch.float32):
+    """Rays of given pixels of one view, as ``Dataset.gen_random_rays_patches_at`` builds them (reference src/dataset/dataset.py:244-287:
+    p = K^-1 [x, y, 1], rays_v = R (p / |p|), rays_o = camera centre, depth_scale = the z component of p / |p|), in fp32 torch ops on
+    the CPU.  tests/golden/make_goldens.py:g15 checks it against the reference method itself before it records the training run that
+    uses it.  -> rays_o (n,3), rays_v (n,3), depth_scale (n,1), edge (n,1)."""
+    K = torch.tensor(meta["frames"][img_idx]["intrinsics"], dtype=dtype)
+    P = torch.tensor(meta["frames"][img_idx]["camtoworld"], dtype=dtype)[:4, :4]
+    px = torch.as_tensor(np.asarray(px)).long()
+    py = torch.as_tensor(np.asarray(py)).long()
+    e = torch.as_tensor(np.asarray(edges), dtype=dtype)
+    if e.dim() == 4:
+        e = e[..., 0]
+    edge = e[img_idx][(py, px)].reshape(-1, 1)
+    p = torch.stack([px, py, torch.ones_like(py)], dim=-1).to(dtype)
+    p = torch.matmul(torch.inverse(K)[None, :3, :3], p[:, :, None]).squeeze(-1)
+    p_norm = torch.linalg.norm(p, ord=2, dim=-1, keepdim=True)
+    pn = p / p_norm
+    rays_v = torch.matmul(P[None, :3, :3], pn[:, :, None]).squeeze(-1)
+    rays_o = P[None, :3, 3].expand(rays_v.shape)
+    return rays_o.contiguous(), rays_v.contiguous(), pn[:, 2:3].contiguous(), edge
+
+
+def convergence_batch(meta, edges, n_rays: int, seed: int, held_out: int = 0):
+    """One training batch of the recorded convergence run (golden g15): a view != held_out, half of the pixels uniform, half uniform over the
+    view's edge pixels (edge > 0.1) - a seeded (NumPy PCG64) stand-in for the host draws of dataset.py:228-243.  -> (img_idx, px, py)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    n_img = len(meta["frames"])
+    img = int(rng.choice([i for i in range(n_img) if i != held_out]))
+    H, W = int(meta["height"]), int(meta["width"])
+    e = np.asarray(edges)[img].reshape(H, W)
+    half = n_rays // 2
+    px, py = rng.integers(0, W, size=half), rng.integers(0, H, size=half)
+    ys, xs = np.nonzero(e > 0.1)
+    k = rng.integers(0, len(ys), size=n_rays - half)
+    return img, np.concatenate([px, xs[k]]), np.concatenate([py, ys[k]])

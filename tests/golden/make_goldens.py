@@ -371,6 +371,111 @@ def g12_training_steps():
     save("g12_training_steps", **d)
 
 
+def g15_convergence():
+    """BASELINE config C5 in miniature, recorded from the REFERENCE's own classes: 1000 optimizer steps of the loop of
+    runner_udf.py:63-168 (render under autograd, EdgeLoss, loss assembly, loss.backward(), torch.optim.Adam with the runner's parameter
+    groups and schedules, iteration axis compressed) on a MULTI-VIEW CONSISTENT target - the projections of one 3D wire frame
+    (emap_amd.synthetic.make_wireframe_scene) - from the reference's own seeded geometric initialisation, followed by the reference's
+    render of a HELD-OUT view.  The rays of a batch are the reference's rays (synthetic.scene_rays, checked here against
+    Dataset.gen_random_rays_patches_at on the same pixels); the pixel draws come from this repo's seeded generator
+    (synthetic.convergence_batch).  What the GPU test compares: the loss curve, the held-out view's edge map and its PSNR of a model
+    trained by the HIP path on the same batches and schedules."""
+    import types
+    sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+    from src.dataset.dataset import Dataset  # reference
+    n_views, HW, held_out = 8, 40, 0
+    meta, edges = synthetic.make_wireframe_scene(n_images=n_views, H=HW, W=HW)
+    K = torch.stack([torch.tensor(f["intrinsics"], dtype=torch.float32) for f in meta["frames"]])
+    P = torch.stack([torch.tensor(f["camtoworld"], dtype=torch.float32) for f in meta["frames"]])
+    e = torch.from_numpy(edges).float()
+    ns_ = types.SimpleNamespace(edges=e, masks=torch.ones(n_views, HW, HW, 3), intrinsics_all=K, intrinsics_all_inv=torch.inverse(K), pose_all=P,
+                                H=HW, W=HW, image_pixels=HW * HW, device=torch.device("cpu"))
+    # the ray construction used below IS the reference's: same numbers as Dataset.gen_random_rays_patches_at on the same pixels
+    img, px, py = synthetic.convergence_batch(meta, edges, 64, seed=1, held_out=held_out)
+    q = [torch.from_numpy(px), torch.from_numpy(py)]
+    orig_randint = torch.randint
+    torch.randint = lambda low=0, high=None, size=None, **k: q.pop(0)
+    try:
+        smp = Dataset.gen_random_rays_patches_at(ns_, img, 64, importance_sample=False)
+    finally:
+        torch.randint = orig_randint
+    ro, rv, ds, ed = synthetic.scene_rays(meta, edges, img, px, py)
+    assert torch.equal(ro, smp["rays"]["rays_o"]) and torch.equal(rv, smp["rays"]["rays_v"]) and torch.equal(ed, smp["rays"]["edge"])
+    assert torch.equal(ds, smp["depth_scale"])
+
+    kw = NETS["d8w256L10"][0]          # the architecture of every EMAP conf (d4 w128 from this initialisation spends the run on its eikonal term)
+    ns, ni, steps_up, N, n_steps = 32, 32, 4, 256, 1000
+    torch.manual_seed(4321)
+    net = UDFNetwork(scale=1.0, geometric_init=True, weight_norm=True, udf_type="abs", **kw)       # the reference's own initialisation
+    init = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    r, dev, bet = make_renderer(net, ns, ni, steps_up)
+    near, far = float(meta["scene_box"]["near"]), float(meta["scene_box"]["far"])
+    lr, lr_geo, alpha, warm_up_end, end_iter, anneal_end = 5e-4, 1e-4, 0.05, 20, n_steps, 200
+    edge_weight, igr_weight, igr_ns_weight = 1.0, 0.1, 0.0
+    opt = torch.optim.Adam([{"params": list(net.parameters()), "lr": lr_geo},
+                            {"params": list(dev.parameters()) + list(bet.parameters())}, {"params": []}], lr=lr)
+    loss_fn = EdgeLoss("mse")
+    losses, edge_losses, lrs = [], [], []
+
+    def render_view(idx):
+        ys, xs = np.mgrid[0:HW, 0:HW]
+        ro_, rv_, ds_, ed_ = synthetic.scene_rays(meta, edges, idx, xs.reshape(-1), ys.reshape(-1))
+        outs = []
+        for h in range(0, HW * HW, 400):
+            nn = ro_[h:h + 400].shape[0]      # (n,1) near / far: with python floats and perturb_overwrite = 0 the reference's z_vals stay (1, n_samples)
+            o = r.render(ro_[h:h + 400], rv_[h:h + 400], torch.full((nn, 1), near), torch.full((nn, 1), far), ds_[h:h + 400], cos_anneal_ratio=1.0,
+                         perturb_overwrite=0, flip_saturation=0.0)
+            outs.append(o["edge"].detach())
+        img_ = torch.cat(outs)
+        mse = float(((img_ - ed_) ** 2).mean())
+        return img_.reshape(HW, HW), 10.0 * np.log10(1.0 / max(mse, 1e-12))
+
+    before, psnr_before = render_view(held_out)
+    import time
+    t0 = time.time()
+    for it in range(n_steps):
+        f = it / warm_up_end if it < warm_up_end else (np.cos(np.pi * (it - warm_up_end) / (end_iter - warm_up_end)) + 1.0) * 0.5 * (1 - alpha) + alpha
+        if it < warm_up_end * 2:
+            fg = it / (warm_up_end * 2)
+        elif it < end_iter * 0.5:
+            fg = 1.0
+        else:
+            fg = (np.cos(np.pi * (it - end_iter * 0.5) / (end_iter - end_iter * 0.5)) + 1.0) * 0.5 * (1 - alpha) + alpha
+        for g in opt.param_groups[1:]:
+            g["lr"] = lr * f
+        opt.param_groups[0]["lr"] = lr_geo * fg
+        car = float(np.min([1.0, it / anneal_end]))
+        img, px, py = synthetic.convergence_batch(meta, edges, N, seed=5000 + it, held_out=held_out)
+        ro, rv, ds, true_edge = synthetic.scene_rays(meta, edges, img, px, py)
+        out = r.render(ro, rv, torch.full((N, 1), near), torch.full((N, 1), far), ds, cos_anneal_ratio=car, perturb_overwrite=0, flip_saturation=0.0)
+        edge_loss = loss_fn(out["edge"], true_edge) * edge_weight
+        loss = edge_loss + out["gradient_error_near_surface"] * igr_ns_weight + out["gradient_error"] * igr_weight
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss)); edge_losses.append(float(edge_loss)); lrs.append([lr_geo * fg, lr * f])
+        if it % 100 == 99:
+            print(f"  g15 step {it + 1}: loss {np.mean(losses[-100:]):.4f} ({time.time() - t0:.0f} s)", flush=True)
+    after, psnr_after = render_view(held_out)
+    train_img, psnr_train = render_view(3)
+    segs = torch.tensor(synthetic.wireframe_segments(), dtype=torch.float32)
+    tt = torch.linspace(0.05, 0.95, 32).view(1, -1, 1)
+    on = (segs[:, :1] * (1 - tt) + segs[:, 1:] * tt).reshape(-1, 3)
+    udf_on = float(net.udf(on)[0].mean()) if isinstance(net.udf(on), tuple) else float(net.udf(on).mean())
+    d = {"netname": np.array("d8w256L10"), "cfg": np.array([ns, ni, steps_up]), "n_rays": np.array(N), "n_steps": np.array(n_steps),
+         "scene": np.array([n_views, HW, held_out]), "batch_seed0": np.array(5000), "init_seed": np.array(4321),
+         "weights3": np.array([edge_weight, igr_weight, igr_ns_weight]),
+         "schedule": np.array([lr, lr_geo, alpha, warm_up_end, end_iter, anneal_end]), "lrs": np.array(lrs),
+         "loss": np.array(losses), "edge_loss": np.array(edge_losses),
+         "held_out_before": before, "held_out_after": after, "train_view_after": train_img,
+         "psnr": np.array([psnr_before, psnr_after, psnr_train]), "udf_on_wireframe": np.array(udf_on),
+         "variance": np.array(float(dev.variance)), "beta": np.array(float(bet.beta)), "gamma": np.array(float(bet.gamma))}
+    for k, v in init.items():
+        d["init." + k + ".abs_sum"] = v.double().abs().sum()
+    print(f"  g15: held-out PSNR {psnr_before:.2f} -> {psnr_after:.2f} dB, train view {psnr_train:.2f} dB, udf on the wire frame {udf_on:.4f}")
+    save("g15_convergence", **d)
+
+
 def g7_perturb():
     """The perturb path (render() :716-720): ONE (N,1) CPU torch.rand draw shifts every ray."""
     net, _ = build_net("d4w128L10")
@@ -523,6 +628,6 @@ def g11_rays():
 if __name__ == "__main__":
     only = sys.argv[1:]
     for fn in (g1_pe, g2_mlp, g3_sample_pdf, g4_upsample_step, g5_render, g6_training, g7_perturb, g8_scalars, g9_seeded_init,
-               g10_extraction, g11_rays, g12_training_steps, g13_sample_pdf_random, g14_mlp_multires0):
+               g10_extraction, g11_rays, g12_training_steps, g13_sample_pdf_random, g14_mlp_multires0, g15_convergence):
         if not only or fn.__name__ in only:
             fn()

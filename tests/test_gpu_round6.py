@@ -238,3 +238,36 @@ def test_whole_image_in_one_call_equals_the_chunked_schedules():
         assert imgs[None][k].shape[0] == H * W
         assert torch.equal(imgs[None][k], imgs[4096][k]), k
         assert rel(imgs[None][k], imgs[512][k]) <= 5e-4, k
+
+
+# ------------------------------------------------------------------------------------------------ f16x3e: 24-bit sigma' stash
+def test_mode_f16x3e_sits_on_the_fp32_floor_element_wise():
+    """the unorm16 sigma' stash was what separated the reverse sweep from fp32 autograd element-wise (p99.9 of
+    grad_x 5.7e-3 against 6.6e-4 for the reference's own fp32 arithmetic, profiles/r05_elementwise_attribution.txt).  In precision mode
+    f16x3e sigma' now travels as 24-bit fixed point (udf_mlp_rev32.inc, SG24: +50 % stash bytes in that mode only).  Against the fp64 oracle
+    on 8192 random points: max-normalised <= 3e-6 (round 5: 1.3e-5), element-wise p99.9 <= 1.2e-3 (measured 5.9e-4; round 5: 6.7e-3) - the
+    forward-mode kernel (no stash at all) gives 7.4e-7 / 4.1e-4.  And on the reference's own recorded points (g2)."""
+    from conftest import net_state, load_golden
+    from oracle import emap_oracle as O
+    from test_gpu_round5 import _rel, _p999
+    kw, state = net_state("d8w256L10")
+    cfg = O.UDFConfig(d_hidden=256, n_layers=8, multires=10)
+    x = torch.rand(65536, 3, generator=torch.Generator().manual_seed(9)) * 2 - 1
+    uo, go = O.udf_value_and_grad({k: v.double() for k, v in state.items()}, cfg, x[:8192].double())
+    n = emap_amd.UDFNetwork(precision="f16x3e", **kw)
+    n.load_state_dict(state)
+    n = n.to(DEV)
+    with torch.no_grad():
+        u, g = n.hip_udf(x.to(DEV), with_grad=True)                 # 65 536 points: the reverse sweep
+        u1, g1 = n.hip_udf(x.to(DEV), with_grad=True)
+    assert torch.equal(u, u1) and torch.equal(g, g1)
+    e_u, e_g, p999 = _rel(u[:8192], uo), _rel(g[:8192], go), _p999(g[:8192], go)
+    print(f"f16x3e vs fp64 oracle: udf {e_u:.2e}, grad_x max-normalised {e_g:.2e}, element-wise p99.9 {p999:.2e}")
+    assert e_u <= 2e-6 and e_g <= 3e-6 and p999 <= 1.2e-3
+    gold = load_golden("g2_mlp")
+    xg = torch.from_numpy(gold["x"])
+    reps = (10240 + xg.shape[0] - 1) // xg.shape[0]                 # enough points for the reverse-sweep kernel
+    with torch.no_grad():
+        ug, gg = n.hip_udf(xg.repeat(reps, 1).to(DEV), with_grad=True)
+    assert _rel(gg[:xg.shape[0]], torch.from_numpy(gold["d8w256L10.grad"]).reshape(-1, 3)) <= 6e-6
+    assert _rel(ug[:xg.shape[0]], torch.from_numpy(gold["d8w256L10.udf"])) <= 2e-6
