@@ -80,7 +80,7 @@ EMAP_VJP_DECL(bf16) EMAP_VJP_DECL(bf16x3) EMAP_VJP_DECL(f16) EMAP_VJP_DECL(f16x3
 size_t plan_wgrad(const NetLayout&, const VjpLayout&, int, WgradJob*, int*, int*, int*, int*);
 int launch_absmax(const float*, const float*, int64_t, uint32_t*, hipStream_t);
 int launch_wgrad(const NetLayout&, const VjpLayout&, const WgradJob*, int, int, const char*, const char*, float*, int, int,
-                 hipStream_t);
+                 hipStream_t, float scale = 1.0f, int no_bias = 0);
 int launch_wgrad_reduce(const NetLayout&, const WgradJob*, int, const int*, const int*, const float*, const uint32_t*, const float*, int,
                         const float* const*, const float* const*, float* const*, float* const*, float* const*, int, int, float,
                         hipStream_t);
@@ -119,7 +119,8 @@ static VjpPlan plan_vjp(const NetLayout& L, int64_t P, size_t avail = 0) {
     pl.off_slab = off; off += (size_t)pl.sweep_grid * pl.V.s_slab_kb * 1024;
     pl.off_partial = off; off += ((pfl * 4 + 255) & ~(size_t)255);
     pl.off_ldot = off; off += (((size_t)std::max<int64_t>(tiles, 1) * 4 + 255) & ~(size_t)255);
-    const size_t per_tile = ((size_t)pl.V.a_tile_kb + (size_t)pl.V.z_tile_kb) * 1024;
+    // precise weight gradients (L.wgrad_lo): a second pair of stashes for the lo parts of both operand sets
+    const size_t per_tile = ((size_t)pl.V.a_tile_kb + (size_t)pl.V.z_tile_kb) * 1024 * (L.wgrad_lo ? 2 : 1);
     if (avail > 0) {
         const size_t fit = avail > off ? (avail - off) / per_tile : 0;
         const int64_t need = std::min<int64_t>(std::max<int64_t>(tiles, 1), VJP_MIN_CHUNK_TILES);
@@ -127,6 +128,11 @@ static VjpPlan plan_vjp(const NetLayout& L, int64_t P, size_t avail = 0) {
     }
     pl.off_a = off; off += (size_t)pl.chunk_tiles * pl.V.a_tile_kb * 1024;
     pl.off_z = off; off += (size_t)pl.chunk_tiles * pl.V.z_tile_kb * 1024;
+    pl.V.lo_a_delta = pl.V.lo_z_delta = 0;
+    if (L.wgrad_lo) {
+        pl.V.lo_a_delta = (long long)(off - pl.off_a); off += (size_t)pl.chunk_tiles * pl.V.a_tile_kb * 1024;
+        pl.V.lo_z_delta = (long long)(off - pl.off_z); off += (size_t)pl.chunk_tiles * pl.V.z_tile_kb * 1024;
+    }
     pl.total = off;
     return pl;
 }
@@ -134,7 +140,7 @@ static VjpPlan plan_vjp(const NetLayout& L, int64_t P, size_t avail = 0) {
 static size_t vjp_min_bytes(const NetLayout& L, int64_t P) {
     const VjpPlan pl = plan_vjp(L, P);
     const int64_t tiles = (P + VJP_PT - 1) / VJP_PT;
-    const size_t per_tile = ((size_t)pl.V.a_tile_kb + (size_t)pl.V.z_tile_kb) * 1024;
+    const size_t per_tile = ((size_t)pl.V.a_tile_kb + (size_t)pl.V.z_tile_kb) * 1024 * (L.wgrad_lo ? 2 : 1);
     return pl.off_a + (size_t)std::min<int64_t>(std::max<int64_t>(tiles, 1), VJP_MIN_CHUNK_TILES) * per_tile;
 }
 
@@ -162,6 +168,15 @@ static int run_vjp(const NetLayout& L, const void* packed, int prec, const Point
         ProfScope pw(2, st);
         rc = launch_wgrad(L, pl.V, pl.jobs, pl.n_jobs, pl.wgrad_wg, ws + pl.off_a, ws + pl.off_z, partial, nt, chunk > 0 ? 1 : 0, st);
         if (rc) return rc;
+        if (L.wgrad_lo && pl.V.lo_a_delta) {
+            // precise weight gradients: dW = Z_hi A_hi^T + (Z_hi A_lo^T + Z_lo A_hi^T) / LO_SCALE - the two cross terms from the lo stashes, added
+            // to the same K-slice partials (the lo x lo term is below 2^-22 of the product)
+            const float inv_lo = 1.0f / 2048.0f;      // LO_SCALE of the split-fp16 modes (udf_mlp_vjp.inc)
+            rc = launch_wgrad(L, pl.V, pl.jobs, pl.n_jobs, pl.wgrad_wg, ws + pl.off_a + pl.V.lo_a_delta, ws + pl.off_z, partial, nt, 1, st, inv_lo, 1);
+            if (rc) return rc;
+            rc = launch_wgrad(L, pl.V, pl.jobs, pl.n_jobs, pl.wgrad_wg, ws + pl.off_a, ws + pl.off_z + pl.V.lo_z_delta, partial, nt, 1, st, inv_lo, 0);
+            if (rc) return rc;
+        }
         if (tiles == 0) break;
     }
     return launch_wgrad_reduce(L, pl.jobs, pl.n_jobs, pl.job_h, pl.job_pe, partial, absmax, ldot, (int)tiles, out->g_host, out->v_host, out->dg_host,

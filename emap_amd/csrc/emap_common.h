@@ -77,6 +77,7 @@ struct NetLayout {
     //   swm_unit[l]    first unit of forward layer l's hidden-K GEMM (l >= 1; units [pair][S]), -1 if none
     //   swm_t_unit[l]  first unit of reverse step b = l (rows = input features of layer l, K = its output features), -1 if none
     int32_t sweep_mx, swm_off_bytes, swm_units;
+    int32_t wgrad_lo;      // 1: the weight-gradient GEMMs multiply hi + lo parts of both operands (three passes; precision mode f16x3e, round 6)
     int32_t swm_unit[EMAP_MAX_LIN], swm_t_unit[EMAP_MAX_LIN];
     LayerDesc layer[EMAP_MAX_LIN];
 };
@@ -221,6 +222,9 @@ struct VjpLayout {
     int32_t z_rt[EMAP_MAX_LIN], z_off[EMAP_MAX_LIN];           // same for the Z block
     int32_t s_off[EMAP_MAX_LIN];                               // KiB offset of layer l's sigma' inside a workgroup's slab
     int32_t a_tile_kb, z_tile_kb, s_slab_kb;
+    // precise weight gradients (NetLayout::wgrad_lo; precision mode f16x3e): the sweep also leaves the LO parts of both operand sets, in the same
+    // layout, lo_a_delta / lo_z_delta bytes behind the hi parts' stashes (0 = not stashed)
+    long long lo_a_delta, lo_z_delta;
 };
 void build_vjp_layout(const NetLayout& L, VjpLayout* V);
 // one weight-gradient GEMM job (wgrad.hip)

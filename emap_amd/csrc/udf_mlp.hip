@@ -525,6 +525,9 @@ int build_layout(const EmapNetConfig* cfg, int prec, NetLayout* L) {
     L->r32_t_frag_off_bytes = L->r32_frag_off_bytes + frag * FRAG_BYTES;
     // MX operands of the training sweep (emap_common.h): hidden-K GEMMs of the forward layers 1 .. n_lin-1 (the last layer's one
     // real row included: its x_lo fragments no longer exist in the sweep's exchange buffer) and of the reverse steps n_lin-2 .. 1
+    // precise weight gradients: hi + lo parts of both operands of dW = sum Z A^T (wgrad.hip: three passes over twice the stash).  The mode without
+    // MX fp6 anywhere (f16x3e) is the one that asks for margin; there the sweep is the f16 one, whose lo fragments are f16 as well.
+    L->wgrad_lo = (prec == EMAP_PREC_F16X3E && L->is_f16 && L->nparts == 2) ? 1 : 0;
     L->sweep_mx = (EMAP_SWEEP_MX && L->is_f16 && L->nparts == 2 && H == 256 && prec != EMAP_PREC_F16X3E && L->has_rev) ? 1 : 0;
     L->swm_units = 0;
     L->swm_off_bytes = (int32_t)(((size_t)L->r32_t_frag_off_bytes + (size_t)tf * FRAG_BYTES + 255) & ~(size_t)255);
@@ -551,7 +554,10 @@ void build_vjp_layout(const NetLayout& L, VjpLayout* V) {
     }
     V->a_tile_kb = a; V->z_tile_kb = z;
     (void)s;
-    V->s_slab_kb = (L.n_lin - 1) * (L.H / 32) * 4;   // per workgroup: [hidden layer][tile pair][4 x 64 lanes x 16 B] lane-linear (a', sigma')
+    // per workgroup: [hidden layer][tile pair][4 x 64 lanes x 16 B] lane-linear (a' as f16 / bf16 hi part, sigma' as unorm16); the f16 sweep of the
+    // split-fp16 modes adds two planes with the lo parts of a' (udf_mlp_vjp.inc, SLABLO)
+    const bool slablo = !L.sweep_mx && L.is_f16 && L.nparts == 2;
+    V->s_slab_kb = (L.n_lin - 1) * (L.H / 32) * (slablo ? 6 : 4);
 }
 
 __global__ __launch_bounds__(256) void pack_all_kernel(const PackArgs a, unsigned nb0, unsigned nb1, unsigned nb2) {

@@ -54,6 +54,10 @@ struct WgradArgs {
     float* partial;
     int32_t n_tiles, n_jobs, a_tile_kb, z_tile_kb;
     int32_t accumulate;         // 1: add to the partials already there (second and later chunks of a launch)
+    // precise weight gradients (three passes per chunk: hi x hi, Z_hi x A_lo, Z_lo x A_hi): this pass's factor (1 or 1 / LO_SCALE) and whether
+    // its Z operand contributes to the bias sums (not in the Z_hi x A_lo pass: the hi x hi pass has counted Z_hi already)
+    float scale;
+    int32_t no_bias;
     WgradJob job[WGRAD_MAX_JOBS];
 };
 
@@ -96,15 +100,15 @@ __device__ __forceinline__ void wgrad_store(const WgradArgs& a, const WgradJob& 
             for (int c = 0; c < CT; ++c) {
                 if (c < J.a_ct) {
                     f32x4* dst = reinterpret_cast<f32x4*>(pb + ((size_t)rt * J.a_ct + c) * 256 + lane * 4);
-                    *dst = a.accumulate ? (*dst + acc[i][c]) : acc[i][c];
+                    *dst = a.accumulate ? (*dst + acc[i][c] * a.scale) : acc[i][c] * a.scale;
                 }
             }
         }
     }
-    if (J.bias_off >= 0) {
+    if (J.bias_off >= 0 && !a.no_bias) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            float v = bsum[i];
+            float v = bsum[i] * a.scale;
             v += __shfl_xor(v, 16);
             v += __shfl_xor(v, 32);
             const int rt = wave + 8 * i;
@@ -502,10 +506,10 @@ int launch_absmax(const float* du, const float* dg, int64_t P, uint32_t* out, hi
 }
 
 int launch_wgrad(const NetLayout& L, const VjpLayout& V, const WgradJob* jobs, int n_jobs, int total_wg, const char* stash_a,
-                 const char* stash_z, float* partial, int n_tiles, int accumulate, hipStream_t st) {
+                 const char* stash_z, float* partial, int n_tiles, int accumulate, hipStream_t st, float scale, int no_bias) {
     WgradArgs a;
     memset(&a, 0, sizeof(a));
-    a.stash_a = stash_a; a.stash_z = stash_z; a.partial = partial;
+    a.stash_a = stash_a; a.stash_z = stash_z; a.partial = partial; a.scale = scale; a.no_bias = no_bias;
     a.n_tiles = n_tiles; a.n_jobs = n_jobs; a.a_tile_kb = V.a_tile_kb; a.z_tile_kb = V.z_tile_kb; a.accumulate = accumulate;
     for (int i = 0; i < n_jobs; ++i) a.job[i] = jobs[i];
     constexpr size_t lds = (size_t)(WGRAD_DEPTH + 1) * 32 * 1024;   // NST stages of (16 A + 16 Z) KiB

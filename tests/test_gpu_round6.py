@@ -271,3 +271,94 @@ def test_mode_f16x3e_sits_on_the_fp32_floor_element_wise():
         ug, gg = n.hip_udf(xg.repeat(reps, 1).to(DEV), with_grad=True)
     assert _rel(gg[:xg.shape[0]], torch.from_numpy(gold["d8w256L10.grad"]).reshape(-1, 3)) <= 6e-6
     assert _rel(ug[:xg.shape[0]], torch.from_numpy(gold["d8w256L10.udf"])) <= 2e-6
+
+
+# ------------------------------------------------------------------------------------------------ f16x3e: precise weight gradients
+@pytest.mark.parametrize("ci", [0, 1, 2, 3])
+def test_f16x3e_parameter_gradients_meet_1e4_on_the_reference_samples(ci):
+    """dL/dtheta of the default mode is 5.9e-4 of each tensor's maximum (wgrad multiplies the f16 hi parts of its
+    operands; gate 1e-3).  Precision mode f16x3e (no MX fp6 anywhere, 24-bit sigma') now also stashes the lo parts of both operand sets and
+    forms dW = Z_hi A_hi^T + (Z_hi A_lo^T + Z_lo A_hi^T) / 2^11 in three passes of the weight-gradient kernel: north_star's 1e-4 on all 27
+    (15) tensors of the four g6 cases recorded from the reference's own loss.backward()."""
+    from conftest import load_golden
+    from test_gpu_backward import _render_bwd_on_reference_samples, _cmp
+    from test_gpu_parity import t
+    g = load_golden(f"g6_training_{ci}")
+    loss, got, extra = _render_bwd_on_reference_samples(g, "f16x3e")
+    assert loss == pytest.approx(float(g["loss"]), rel=1e-4)
+    ref = {k[5:]: t(g[k]) for k in g if k.startswith("grad.lin")}
+    w = _cmp(got, ref, 1e-4, f"g6_{ci} f16x3e")
+    print(f"g6_training_{ci}, f16x3e: worst rel-to-max error of dL/dtheta {w:.2e}")
+    gmax = max(float(v.abs().max()) for v in ref.values())
+    for k in ("variance", "beta", "gamma"):
+        r_ = float(t(g["grad." + k]))
+        assert abs(float(extra[k]) - r_) <= 1e-3 * abs(r_) + 1e-6 * gmax, (k, float(extra[k]), r_)
+
+
+# ------------------------------------------------------------------------------------------------ C5 in miniature: against a reference-trained model
+@pytest.mark.timeout(1200)
+def test_hip_training_run_matches_the_reference_trained_model_on_a_held_out_view():
+    """BASELINE config C5 ("full training loop ... edge-accuracy parity vs reference checkpoint"), in miniature and
+    without a dataset: golden g15 is a 1000-step training run of the REFERENCE's own classes (tests/golden/make_goldens.py:g15_convergence -
+    d8 w256 from the reference's seeded geometric initialisation, the runner's Adam groups and schedules, 256 rays per step from 7 views
+    of a multi-view consistent wire frame) and its render of the held-out eighth view.  The same run on the HIP path (native Trainer: fused
+    forward, hand-written backward, fused Adam), same batches, same schedules, then the same held-out render:
+      * the loss curve tracks the reference's: means over windows of 100 steps within 25 % everywhere (measured: up to 18 % apart in the middle of
+        the run - two trajectories through a chaotic phase; the sampler's discontinuity makes single steps differ) and within 5 % over the last
+        300 steps (measured 0.01 ... 0.4 %: both runs settle on the same curve),
+      * the held-out view's PSNR against the ground-truth edge map is within 0.5 dB of the reference-trained model's,
+      * the two models' held-out edge maps agree to RMS 0.04 of a [0, 1] image (measured 0.025: a quarter of either model's own RMS error against
+        the ground truth, 0.105 at 19.6 dB - two optimisation trajectories, not two evaluations of one model)."""
+    from conftest import load_golden
+    from test_gpu_parity import mk_renderer, t
+    g = load_golden("g15_convergence")
+    ns, ni, steps_up = [int(v) for v in g["cfg"]]
+    N, n_steps = int(g["n_rays"]), int(g["n_steps"])
+    n_views, HW, held_out = [int(v) for v in g["scene"]]
+    lr, lr_geo, alpha, warm_up_end, end_iter, anneal_end = [float(v) for v in g["schedule"]]
+    ew, igr, igr_ns = [float(v) for v in g["weights3"]]
+    meta, edges = synthetic.make_wireframe_scene(n_images=n_views, H=HW, W=HW)
+    kw = dict(d_in=3, d_out=1, d_hidden=256, n_layers=8, skip_in=(4,), multires=10, bias=0.5)
+    torch.manual_seed(int(g["init_seed"]))                       # the reference's constructor under the same seed (g9 pins the RNG consumption)
+    net = emap_amd.UDFNetwork(scale=1.0, geometric_init=True, weight_norm=True, udf_type="abs", precision="f16x3", **kw)
+    for k, v in net.state_dict().items():
+        assert float(v.double().abs().sum()) == pytest.approx(float(g["init." + k + ".abs_sum"]), rel=1e-12), k
+    net = net.to(DEV)
+    r = mk_renderer(net, ns, ni, steps_up)
+    tr = Trainer(r, lr_geo=lr_geo, lr=lr, edge_weight=ew, igr_weight=igr, igr_ns_weight=igr_ns)
+    near, far = float(meta["scene_box"]["near"]), float(meta["scene_box"]["far"])
+    losses = []
+    for it in range(n_steps):
+        tr.optimizer.param_groups[0]["lr"], tr.optimizer.param_groups[1]["lr"] = float(g["lrs"][it][0]), float(g["lrs"][it][1])
+        img, px, py = synthetic.convergence_batch(meta, edges, N, seed=int(g["batch_seed0"]) + it, held_out=held_out)
+        ro, rv, ds, true_edge = synthetic.scene_rays(meta, edges, img, px, py)
+        b = {"rays_o": ro.to(DEV), "rays_d": rv.to(DEV), "near": torch.full((N, 1), near, device=DEV), "far": torch.full((N, 1), far, device=DEV),
+             "depth_scale": ds.to(DEV), "cos_anneal_ratio": float(np.min([1.0, it / anneal_end])), "flip_saturation": 0.0, "perturb_overwrite": 0}
+        losses.append(tr.step(b, true_edge.to(DEV)))
+    tr.check_errors()
+    hl = torch.stack(losses)[:, 0].cpu().double().numpy()
+    rl = np.asarray(g["loss"], dtype=np.float64)
+    win = 100
+    hm, rm = hl.reshape(-1, win).mean(1), rl.reshape(-1, win).mean(1)
+    print("loss, means over windows of 100 steps  reference:", np.round(rm, 4), " HIP:", np.round(hm, 4))
+    assert np.all(np.abs(hm - rm) <= 0.25 * rm) and np.all(np.abs(hm - rm)[-3:] <= 0.05 * rm[-3:])
+    # the held-out view, rendered like the reference rendered it (perturb_overwrite = 0, cos_anneal_ratio = 1)
+    ys, xs = np.mgrid[0:HW, 0:HW]
+    ro, rv, ds, gt = synthetic.scene_rays(meta, edges, held_out, xs.reshape(-1), ys.reshape(-1))
+    n = ro.shape[0]
+    with torch.no_grad():
+        o = r.render(ro.to(DEV), rv.to(DEV), torch.full((n, 1), near, device=DEV), torch.full((n, 1), far, device=DEV), ds.to(DEV),
+                     cos_anneal_ratio=1.0, perturb_overwrite=0, flip_saturation=0.0)
+    img_h = o["edge"].reshape(HW, HW).cpu()
+    img_r = t(g["held_out_after"])
+    gt = gt.reshape(HW, HW)
+    psnr = lambda a: 10.0 * np.log10(1.0 / max(float(((a - gt) ** 2).mean()), 1e-12))
+    p_h, p_r = psnr(img_h), psnr(img_r)
+    rms = float(((img_h - img_r) ** 2).mean().sqrt())
+    print(f"held-out view: PSNR vs ground truth  HIP-trained {p_h:.2f} dB, reference-trained {p_r:.2f} dB (recorded {float(g['psnr'][1]):.2f}; before training "
+          f"{float(g['psnr'][0]):.2f}); RMS difference of the two models' edge maps {rms:.4f}")
+    assert p_r == pytest.approx(float(g["psnr"][1]), abs=1e-6)
+    assert abs(p_h - p_r) <= 0.5 and p_h >= float(g["psnr"][0]) + 10.0
+    assert rms <= 0.04
+    assert float(r.deviation_network.variance) == pytest.approx(float(g["variance"]), rel=5e-2)
+    assert float(r.beta_network.beta) == pytest.approx(float(g["beta"]), rel=5e-2)
