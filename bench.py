@@ -39,7 +39,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 # the PMC passes of the dominant kernels recorded by scripts/profile_round.sh for this round's kernels (static: not measured in a bench run)
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r05_traffic.json")
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r06_traffic.json")
 sys.path.insert(0, ROOT)
 
 F_POINT = 918016          # FLOP per MLP point-forward, d8 w256 (SURVEY par. 7.0 / 8d)
