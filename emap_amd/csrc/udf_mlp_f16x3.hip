@@ -16,3 +16,8 @@ int launch_is_f16x3(const NetLayout& L, const void* packed, const IsLaunch& q, h
     return launch_is_mode<EMAP_PREC_F16X3>(L, packed, q, st, err);
 }
 }  // namespace emap
+#ifdef EMAP_TIMELINE      // probe builds only
+extern "C" int emap_debug_fs2_timeline(long long* dst, int n) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(emap::emap_ftl_buf), (size_t)n * sizeof(long long));
+}
+#endif
