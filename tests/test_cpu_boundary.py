@@ -462,3 +462,32 @@ def test_ctypes_structs_match_the_header_field_for_field(tmp_path):
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         n_members = sum(len(decl.split(",")) for decl in body.split("{", 1)[1].split(";") if decl.strip())
         assert n_members == len(cls._fields_), (cname, n_members, len(cls._fields_))
+
+
+def test_round6_switches_and_argument_checks():
+    """ABI 9 host-only entry points: the process-wide switches return their previous value; the one-shot all-reduce's time-out is range-checked."""
+    L = _lib.lib()
+    assert L.emap_set_fused_composite(0) == 1 and L.emap_set_fused_composite(1) == 0 and L.emap_set_fused_composite(1) == 1
+    prev = L.emap_set_fused_sampling(2)
+    assert prev in (0, 1, 2) and L.emap_set_fused_sampling(7) == 2 and L.emap_set_fused_sampling(prev) == 2      # values above 2 clamp to 2
+    assert L.emap_ar_set_timeout_ms(0) == -1 and b"ar_set_timeout_ms" in L.emap_last_error()
+    assert L.emap_ar_set_timeout_ms(10 ** 7) == -1
+    assert L.emap_ar_set_timeout_ms(10000) == 0
+
+
+def test_render_workspace_grows_with_the_arrival_counters_and_the_24_bit_stash():
+    """emap_render_workspace_bytes (ABI 9): + one int32 arrival counter per ray (fused compositing tail) and sigma' slabs with three bytes reserved per
+    value (precision mode f16x3e carries 24 bits; the 16-bit modes use two of them): 512 workgroups x 8 layers x 8 row tiles x 6 KiB + 8 KiB each."""
+    L = _lib.lib()
+    cfg = _lib.NetConfig(256, 9, 4, 10, 1, 0, 1.0)
+    def ws(n_rays):
+        p = _lib.RenderParams()
+        p.n_rays, p.n_samples, p.n_importance, p.up_sample_steps = n_rays, 64, 64, 4
+        n = C.c_size_t()
+        assert L.emap_render_workspace_bytes(C.byref(cfg), _lib.PRECISIONS["f16x3"], C.byref(p), C.byref(n)) == 0
+        return n.value
+    a, b = ws(512), ws(1024)
+    slabs = 512 * (8 * 8 * 6144 + 8192)
+    assert a > slabs and b > a
+    per_ray = (b - a) / 512
+    assert 4 * (4 * 128 + 3 * 16 + 8) + 4 <= per_ray <= 4 * (4 * 128 + 3 * 16 + 8) + 4 + 8       # z/udf buffers x 4, new samples x 3, partials, + the counter
