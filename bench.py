@@ -866,6 +866,29 @@ def main():
                                                           + (f" (live measurement unavailable: {live_note})" if live_note else ""))
             except Exception:
                 pass
+        if world == 1 and a.mode == "render" and launch.startswith("hipGraph") and not a.no_other_modes:
+            # the headline replays the SAME rays from one graph (rays, weights and the sigma' slabs stay cache-resident).  Beside
+            # it: the same graph fed a DIFFERENT ray batch at every replay (8 batches resident in HBM, copied into the graph's static inputs:
+            # four small device-to-device copies per step, inside the timed region)
+            try:
+                from emap_amd import synthetic as _syn
+                batches = []
+                for sd in range(101, 109):
+                    rb = [t.contiguous().to(dev) for t in _syn.make_rays(rays, seed=sd)]
+                    batches.append((rb, _syn.make_t_rand(rays, seed=sd + 50).to(dev)))
+                k = [0]
+
+                def rot():
+                    rb, trb = batches[k[0] % len(batches)]
+                    k[0] += 1
+                    return step(rb[0], rb[1], rb[2], rb[3], rb[4], t_rand=trb)
+                dt_r, med_r = _timed(rot, max(a.steps, 40), 10)
+                r.check_errors()
+                line["rotating_rays"] = {"ms_per_step": dt_r * 1e3, "ms_per_step_median": med_r, "value": rays * S / dt_r, "unit": "ray-samples/s",
+                                         "batches": len(batches), "note": "same hipGraph, a different 512-ray batch copied in before every replay"}
+                step(ro, rd, near, far, ds, t_rand=tr)      # back to the headline batch
+            except Exception as e:
+                line["rotating_rays"] = {"error": repr(e)}
         if not a.no_other_modes and world == 1 and a.mode == "render":
             other = {}
             for mode in MODE_DTYPE:
