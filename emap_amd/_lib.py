@@ -23,7 +23,7 @@ PREC_F16X3E = 5    # f16x3 with f16 cross terms in both sweeps of the value+grad
 PRECISIONS = {"bf16": PREC_BF16, "bf16x3": PREC_BF16X3, "f16": PREC_F16, "f16x3": PREC_F16X3, "f16x3m": PREC_F16X3M, "f16x3e": PREC_F16X3E}
 UDF_TYPES = {"abs": 0, "square": 1, "sdf": 2}
 MAX_LIN = 12
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 F_NAN_SAMPLES = 1
 F_NAN_GRADERR = 2
@@ -81,6 +81,7 @@ SYMBOLS = {
     "emap_set_grad_mode": (C.c_int, [C.c_int]),
     "emap_set_fused_sampling": (C.c_int, [C.c_int]),
     "emap_set_fused_composite": (C.c_int, [C.c_int]),
+    "emap_set_value_tile_mode": (C.c_int, [C.c_int]),
     "emap_packed_bytes": (C.c_int, [C.POINTER(NetConfig), C.c_int, C.POINTER(C.c_size_t)]),
     "emap_pack_weights": (C.c_int, [C.POINTER(NetConfig), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), _P, C.c_int, _P]),
     "emap_udf_fwd": (C.c_int, [C.POINTER(NetConfig), _P, C.c_int, _P, C.c_int64, _P, _P]),

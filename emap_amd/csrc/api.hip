@@ -241,6 +241,7 @@ int emap_set_fused_sampling(int on) { return set_fused_sampling(on); }
 int emap_set_fused_composite(int on) { return g_fused_composite.exchange(on ? 1 : 0, std::memory_order_relaxed); }
 const char* emap_last_error(void) { return g_err; }
 int emap_set_grad_mode(int mode) { return set_grad_mode(mode); }
+int emap_set_value_tile_mode(int on) { return set_value_tile_mode(on); }
 
 int emap_packed_bytes(const EmapNetConfig* cfg, int prec, size_t* bytes) {
     NetLayout L;

@@ -195,6 +195,8 @@ constexpr int IS_NOT_FUSED = 1;
 int launch_importance(const NetLayout& L, const void* packed, int prec, const IsLaunch& q, hipStream_t st, int32_t* err_flags);
 int set_fused_sampling(int on);    // process-wide switch (tests, A/B): 0 chain, 1 fused where the launcher's size rule picks it, 2 fused at every size; returns the previous value
 int fused_sampling_mode();
+int set_value_tile_mode(int on);   // wide value launches (>= 512 tiles of 64 points, split modes, d_hidden 256): 1 = the 32x32 forward sweep (udf_mlp_rev32.inc, VAL), 0 = udf_mlp_fs2_kernel; returns the previous value
+int value_tile_mode();
 // fuse (value + grad_x launches that run the reverse-sweep kernel only - mlp_uses_rev()): the workgroup that writes the last point of a ray
 // composites that ray (BASELINE config C2: "fused MLP + composite"); the caller then launches only the cross-ray reduction.
 int launch_mlp(const NetLayout& L, const void* packed, int prec, const PointSource& src, int64_t P,

@@ -650,6 +650,20 @@ static std::atomic<int> g_fused_sampling{fused_sampling_from_env()};
 int set_fused_sampling(int on) { return g_fused_sampling.exchange(on < 0 ? 0 : (on > 2 ? 2 : on), std::memory_order_relaxed); }
 int fused_sampling_mode() { return g_fused_sampling.load(std::memory_order_relaxed); }
 
+// Wide value launches as the forward sweep of the 32x32 kernel (udf_mlp_rev32.inc, VAL).  OFF by default - measured round 6, same box, interleaved
+// (profiles/r06_value32_ab.txt): one 32 768-point launch 95.6 vs 97.4 us, but +3 ... +5 % from 65 536 points on; render from a graph 0.5387 vs
+// 0.5435 ms at 512 rays (-0.9 %), 1.019 vs 1.019 at 1024, 3.998 vs 4.135 at 4096 (-3.3 %: the cooler value kernels leave the final pass more
+// clock under the package power cap).  Its sums run in another order than the 16x16 kernel's (udf differs by <= 4.5e-7 of the maximum): a render's
+// z_vals would depend on whether its launch has 512 tiles - a sub-batch would no longer reproduce its rows bit for bit - for a gain inside the
+// spread of the boxes.  EMAP_VALUE32=1 (read ONCE at load) / emap_set_value_tile_mode(1) turn it on.
+static int value_tile_from_env() {
+    const char* e = getenv("EMAP_VALUE32");
+    return (e && e[0] == '1') ? 1 : 0;
+}
+static std::atomic<int> g_value_tile{value_tile_from_env()};
+int set_value_tile_mode(int on) { return g_value_tile.exchange(on ? 1 : 0, std::memory_order_relaxed); }
+int value_tile_mode() { return g_value_tile.load(std::memory_order_relaxed); }
+
 int launch_importance(const NetLayout& L, const void* packed, int prec, const IsLaunch& q, hipStream_t st, int32_t* err_flags) {
     if (!g_fused_sampling.load(std::memory_order_relaxed)) return IS_NOT_FUSED;
     switch (prec) {

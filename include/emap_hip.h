@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EMAP_ABI_VERSION 9
+#define EMAP_ABI_VERSION 10
 
 /* error codes */
 #define EMAP_OK 0
@@ -203,6 +203,13 @@ int emap_set_fused_sampling(int on);
  * 0 restores the separate compositing launch (same results bit for bit: tests, A/B; EMAP_FUSED_COMPOSITE=0 at load).  Process-wide;
  * returns the previous value. */
 int emap_set_fused_composite(int on);
+/* ABI v10: 1 = the wide value launches (the coarse pass of a render: UDFNetwork.udf on n_samples points per ray, udf_renderer_blending.py:722-725,
+ * udf_model.py:90-116; >= 32 768 points, split-fp16 / split-bf16 modes at d_hidden = 256 except f16x3m) run the FORWARD sweep of the 32x32x16
+ * value + grad_x kernel as a value kernel (csrc/udf_mlp_rev32.inc, VAL: same tile geometry as the 16x16x32 value kernel, half the MFMA
+ * instructions, pinned K-loop).  Default 0 (udf_mlp_fs2_kernel for every value launch; EMAP_VALUE32=1 at load turns it on): measured -0.9 % /
+ * 0 / -3.3 % on the 512 / 1024 / 4096-ray render, and the two forms sum a GEMM's products in different orders - udf agrees to fp32 rounding
+ * (tests), not bit for bit, so with it a render's z_vals depend on the launch size.  Process-wide; returns the previous value. */
+int emap_set_value_tile_mode(int on);
 int emap_render_workspace_bytes(const EmapNetConfig* cfg, int prec, const EmapRenderParams* p, size_t* bytes);
 int emap_render_fwd(const EmapNetConfig* cfg, const void* packed, int prec, const EmapRenderParams* p,
                     const float* rays_o, const float* rays_d, const float* near, const float* far,

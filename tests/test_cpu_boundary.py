@@ -473,6 +473,10 @@ def test_round6_switches_and_argument_checks():
     assert L.emap_ar_set_timeout_ms(0) == -1 and b"ar_set_timeout_ms" in L.emap_last_error()
     assert L.emap_ar_set_timeout_ms(10 ** 7) == -1
     assert L.emap_ar_set_timeout_ms(10000) == 0
+    # ABI 10: the 32x32 forward sweep for the wide value launches - off unless EMAP_VALUE32=1 was set at load
+    import os
+    d = 1 if os.environ.get("EMAP_VALUE32", "")[:1] == "1" else 0
+    assert L.emap_set_value_tile_mode(1) == d and L.emap_set_value_tile_mode(0) == 1 and L.emap_set_value_tile_mode(d) == 0
 
 
 def test_render_workspace_grows_with_the_arrival_counters_and_the_24_bit_stash():

@@ -48,6 +48,77 @@ def test_fused_adam_follows_lr_changes_after_load_state_dict():
         assert torch.allclose(pd_, pb, rtol=3e-6, atol=1e-7)
 
 
+# ------------------------------------------------------------------------------------------------ the 32x32 forward sweep as a value kernel (ABI 10, opt-in)
+@pytest.mark.parametrize("prec", ["f16x3", "f16x3e", "bf16x3"])
+def test_value_tile_mode_32x32_forward_sweep_vs_oracle_and_the_16x16_kernel(prec):
+    """emap_set_value_tile_mode(1): value launches of >= 512 tiles of 64 points run udf_mlp_rev32_kernel<.., VAL> (forward sweep only).  udf
+    against the fp64 oracle at the gate of the 16x16 kernel, against that kernel to fp32 rounding, ragged launch sizes around the
+    switch-over, a launch larger than the resident grid; below 512 tiles the switch changes nothing (bit for bit); f16x3m ignores it."""
+    from test_gpu_parity import mk
+    from conftest import net_state
+    from oracle import emap_oracle as O
+    net, state, cfg = mk("d8w256L10", prec)
+    L = _lib.lib()
+    gen = torch.Generator().manual_seed(77)
+    x = (torch.rand(300001, 3, generator=gen) * 2 - 1)
+    xd = x.to(DEV)
+    ref = O.udf_value_and_grad({k: v.double() for k, v in state.items()}, cfg, x[:3000].double())[0].float().reshape(-1)
+    tol = 2e-5 if prec == "bf16x3" else 2e-6
+    try:
+        for P in (32768 - 63, 32768 - 64, 32769, 40037, 300001):
+            outs = {}
+            for mode in (0, 1):
+                L.emap_set_value_tile_mode(mode)
+                with torch.no_grad():
+                    outs[mode] = net.hip_udf(xd[:P])[0].reshape(-1).clone()
+            torch.cuda.synchronize()
+            d = float((outs[0] - outs[1]).abs().max() / outs[0].abs().max())
+            if P <= 32768 - 64:          # 511 tiles of 64: the 16x16 kernel either way
+                assert torch.equal(outs[0], outs[1]), P
+            else:
+                assert 0 < d <= 3 * tol, (P, d)         # another kernel (not bit-equal), the same function
+                e = float((outs[1][:3000].cpu() - ref).abs().max() / ref.abs().max())
+                assert e <= tol, (P, e)
+        netm, _, _ = mk("d8w256L10", "f16x3m")
+        o = {}
+        for mode in (0, 1):
+            L.emap_set_value_tile_mode(mode)
+            with torch.no_grad():
+                o[mode] = netm.hip_udf(xd[:40037])[0].clone()
+        assert torch.equal(o[0], o[1])
+    finally:
+        L.emap_set_value_tile_mode(0)
+
+
+def test_render_with_the_32x32_coarse_pass_vs_reference_golden_and_its_arrival_counters():
+    """A 512-ray render whose coarse pass is the 32x32 forward sweep (it is the render's first launch: it clears the arrival counters of the
+    fused compositing tail) - twice back to back (stale counters would hang or corrupt the second), edge / depth within the bounds of the
+    default path against the 16x16 coarse pass, and every ray composited."""
+    from test_gpu_parity import mk, mk_renderer, rel
+    net, _, _ = mk("d8w256L10", "f16x3")
+    r = mk_renderer(net, 64, 64, 4)
+    ro, rd, near, far, ds = [v.to(DEV) for v in synthetic.make_rays(600, seed=9)]
+    L = _lib.lib()
+    outs = {}
+    try:
+        for mode in (0, 1, 1):
+            L.emap_set_value_tile_mode(mode)
+            with torch.no_grad():
+                o = r.render(ro, rd, near, far, ds, cos_anneal_ratio=1.0, perturb_overwrite=0, flip_saturation=0.9)
+            torch.cuda.synchronize()
+            r.check_errors()
+            outs.setdefault(mode, []).append({k: o[k].clone() for k in ("edge", "depth", "weight_sum", "z_vals", "udf")})
+    finally:
+        L.emap_set_value_tile_mode(0)
+    a, b, c = outs[0][0], outs[1][0], outs[1][1]
+    for k in a:
+        assert torch.equal(b[k], c[k]), k                      # deterministic, counters cleared by the new first launch
+    assert rel(b["edge"], a["edge"]) <= 1e-4 and rel(b["depth"], a["depth"]) <= 3e-4
+    same = float((b["z_vals"] == a["z_vals"]).all(dim=1).float().mean())
+    assert same >= 0.80, same                                   # an ulp of the coarse udf re-samples a few rays (as between two CPUs: DESIGN par. 4)
+    assert float((b["weight_sum"] - a["weight_sum"]).abs().max()) <= 2e-3
+
+
 # ------------------------------------------------------------------------------------------------ fused importance sampling, widened
 def _fused_vs_chain(netname, N, prec, n_samples, n_importance, steps, fused_mode=1):
     """importance_sample (udf_renderer_blending.py:802-841) as ONE launch against the chain of 2 K - 1 launches: every rendered tensor
