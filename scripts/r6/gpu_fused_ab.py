@@ -29,7 +29,11 @@ def timed(fn, steps=60, warmup=20):
     return (time.perf_counter() - t0) / steps * 1e3
 
 
+if len(sys.argv) > 1:      # e.g. "640,64,50,5 768,64,64,4": N, n_samples, n_importance, up_sample_steps
+    shapes_arg = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]]
 shapes = [(512, 64, 64, 4), (1024, 64, 64, 4), (1024, 64, 50, 5), (2048, 64, 64, 4), (2048, 64, 50, 5), (4096, 64, 64, 4), (4096, 64, 50, 5), (8192, 64, 64, 4)]
+if len(sys.argv) > 1:
+    shapes = shapes_arg
 for N, ns, ni, K in shapes:
     r = emap_amd.UDFRendererBlending(None, net, devn, bet, ns, ni, 0, K, 1.0, device=dev)
     ro, rd, near, far, ds = [t.contiguous().to(dev) for t in synthetic.make_rays(N, seed=1)]

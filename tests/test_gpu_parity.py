@@ -656,7 +656,7 @@ def _fused_vs_chain(netname, N, prec):
     L = _lib.lib()
     outs = {}
     try:
-        for fused in (1, 0):
+        for fused in (2, 1, 0):       # 2: the fused kernel whatever the size rule says (round 6: the rule hands 768 ... 1024 rays at m = 16 to the chain), 1: the rule's pick
             L.emap_set_fused_sampling(fused)
             with torch.no_grad():
                 o1 = r.render(ro, rd, near, far, ds, cos_anneal_ratio=1.0, flip_saturation=0.9, t_rand=tr)
@@ -666,9 +666,9 @@ def _fused_vs_chain(netname, N, prec):
             outs[fused] = {tag + k: v.clone() for tag, o in (("jitter.", o1), ("plain.", o2)) for k, v in o.items() if isinstance(v, torch.Tensor)}
     finally:
         L.emap_set_fused_sampling(1)
-    assert set(outs[0]) == set(outs[1]) and "jitter.z_vals" in outs[1] and "plain.z_vals" in outs[1]
+    assert set(outs[0]) == set(outs[1]) == set(outs[2]) and "jitter.z_vals" in outs[1] and "plain.z_vals" in outs[1]
     for k in outs[1]:
-        assert torch.equal(outs[1][k], outs[0][k]), k
+        assert torch.equal(outs[1][k], outs[0][k]) and torch.equal(outs[2][k], outs[0][k]), k
 
 
 def test_perturb_path_and_float_near_far():

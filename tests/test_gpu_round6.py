@@ -90,6 +90,29 @@ def test_value_tile_mode_32x32_forward_sweep_vs_oracle_and_the_16x16_kernel(prec
         L.emap_set_value_tile_mode(0)
 
 
+@pytest.mark.parametrize("prec", ["f16x3", "bf16x3"])
+def test_value_launches_of_8193_to_16384_points_run_one_8_wave_workgroup_per_cu_bit_identically(prec):
+    """Round 6: 129 ... 256 tiles of 64 points run udf_mlp_fs2_kernel<256, .., 4, false, 8> (one 8-wave workgroup per CU, 64-point tile, two exchange
+    buffers).  Every fs2 geometry sums in the same K order: a point's udf is the same bit for bit whichever launch size carries it - ragged last
+    tiles, both ends of the range, the neighbouring rules (8192: two 4-wave workgroups on 32-point tiles; 16385: ditto)."""
+    from test_gpu_parity import mk
+    from oracle import emap_oracle as O
+    net, state, cfg = mk("d8w256L10", prec)
+    gen = torch.Generator().manual_seed(123)
+    x = (torch.rand(20000, 3, generator=gen) * 2.4 - 1.2).to(DEV)
+    with torch.no_grad():
+        base = net.hip_udf(x[:4096])[0].clone()                  # 128 tiles of 32: one 8-wave workgroup per CU on 32-point tiles
+        full = net.hip_udf(x)[0].clone()                         # 20 000 points: 4-wave workgroups, 32-point tiles
+        for P in (8192, 8193, 8256, 10240, 12345, 16321, 16384, 16385):
+            u = net.hip_udf(x[:P])[0]
+            assert u.shape == (P, 1)
+            assert torch.equal(u[:4096], base) and torch.equal(u, full[:P]), P
+    ur = O.udf_value_and_grad(state, cfg, x[8000:9000].cpu())[0]
+    with torch.no_grad():
+        u = net.hip_udf(x[:12345])[0]
+    assert float((u[8000:9000].cpu() - ur).abs().max() / ur.abs().max()) <= (5e-5 if prec == "bf16x3" else 1e-5)
+
+
 def test_render_with_the_32x32_coarse_pass_vs_reference_golden_and_its_arrival_counters():
     """A 512-ray render whose coarse pass is the 32x32 forward sweep (it is the render's first launch: it clears the arrival counters of the
     fused compositing tail) - twice back to back (stale counters would hang or corrupt the second), edge / depth within the bounds of the
@@ -157,8 +180,11 @@ def _fused_vs_chain(netname, N, prec, n_samples, n_importance, steps, fused_mode
     ("d4w128L10", 512, 64, 50, 5), ("d4w128L10", 50, 32, 30, 3),
 ])
 def test_fused_importance_sampling_with_fewer_than_16_new_samples_per_step(netname, N, ns, ni, K):
-    """VERDICT r5 missing #2 / item 4: the fused kernel refused every m != 16 - the reference's default shape among them."""
-    _fused_vs_chain(netname, N, "f16x3", ns, ni, K)
+    """VERDICT r5 missing #2 / item 4: the fused kernel refused every m != 16 - the reference's default shape among them.  (Since the size rule
+    of launch_is_mode hands m <= 12 at >= 6 144 new samples per step back to the chain - measured faster - the fused kernel is FORCED here, mode 2;
+    whatever the rule picks, mode 1, must be bit-identical as well.)"""
+    _fused_vs_chain(netname, N, "f16x3", ns, ni, K, fused_mode=2)
+    _fused_vs_chain(netname, N, "f16x3", ns, ni, K, fused_mode=1)
 
 
 @pytest.mark.parametrize("N,ns,ni,K", [(2048, 64, 64, 4), (4096, 64, 64, 4), (2500, 64, 50, 5)])
@@ -171,7 +197,8 @@ def test_fused_importance_sampling_at_2048_rays_and_more(N, ns, ni, K):
 
 @pytest.mark.parametrize("prec", ["f16x3m", "f16x3e", "bf16x3", "bf16"])
 def test_fused_importance_sampling_m10_in_other_precision_modes(prec):
-    _fused_vs_chain("d8w256L10", 512, prec, 64, 50, 5)
+    _fused_vs_chain("d8w256L10", 512, prec, 64, 50, 5, fused_mode=2)
+    _fused_vs_chain("d8w256L10", 700, prec, 64, 50, 5, fused_mode=1)       # 7 000 new samples per step: the split modes take the chain (size rule)
 
 
 # ------------------------------------------------------------------------------------------------ compositing inside the value + grad_x kernel
