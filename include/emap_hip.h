@@ -194,7 +194,7 @@ int emap_composite_fwd_p(const float* rays_o, const float* rays_d, const float* 
 
 /* ABI v8: emap_render_fwd runs importance_sample (udf_renderer_blending.py:802-841) as ONE launch where the shape allows (ABI 9: 1 <=
  * n_importance / up_sample_steps <= 16 new samples per step; measured launch-size rule in csrc/udf_mlp_kernel.inc:launch_is_mode - round 6:
- * fused up to 512 rays, or for 13 ... 16 new samples per step below 12 288 of them per launch; the chain elsewhere); 0 restores the chain of 2 K - 1 launches (same results bit for bit: tests, A/B), 2 (ABI 9) uses
+ * fused up to 512 rays, the chain of dense launches beyond); 0 restores the chain of 2 K - 1 launches (same results bit for bit: tests, A/B), 2 (ABI 9) uses
  * the fused kernel at every launch size.  Process-wide; returns the previous value. */
 int emap_set_fused_sampling(int on);
 /* ABI v9: emap_render_fwd composites every ray INSIDE the final value + grad_x launch (the workgroup that writes a ray's last point runs

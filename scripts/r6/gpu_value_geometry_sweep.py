@@ -6,7 +6,9 @@ usage: python scripts/r6/gpu_value_geometry_sweep.py [P ...]"""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 Ps = sys.argv[1:] or [str(v) for v in (2048, 3072, 4096, 5120, 6144, 7168, 8192, 10240, 12288, 16384, 18432, 20480, 24576, 28672, 32704, 32768, 40960, 49152, 65536)]
-geoms = {"rule": "0", "1x8": "18", "2x8": "28", "4x8": "48", "2x4": "24", "4x4": "44"}
+geoms = {"rule": "0", "1x8": "18", "2x8": "28", "3x8": "38", "4x8": "48", "5x8": "58", "2x4": "24", "3x4": "34", "4x4": "44"}
+if os.environ.get("GEOMS"):
+    geoms = {k: v for k, v in geoms.items() if k in os.environ["GEOMS"].split(",")}
 res = {}
 for rnd in range(2):
     for name, code in geoms.items():

@@ -91,19 +91,20 @@ def test_value_tile_mode_32x32_forward_sweep_vs_oracle_and_the_16x16_kernel(prec
 
 
 @pytest.mark.parametrize("prec", ["f16x3", "bf16x3"])
-def test_value_launches_of_8193_to_16384_points_run_one_8_wave_workgroup_per_cu_bit_identically(prec):
-    """Round 6: 129 ... 256 tiles of 64 points run udf_mlp_fs2_kernel<256, .., 4, false, 8> (one 8-wave workgroup per CU, 64-point tile, two exchange
-    buffers).  Every fs2 geometry sums in the same K order: a point's udf is the same bit for bit whichever launch size carries it - ragged last
-    tiles, both ends of the range, the neighbouring rules (8192: two 4-wave workgroups on 32-point tiles; 16385: ditto)."""
+def test_value_launch_geometry_table_is_bit_identical_across_its_ranges(prec):
+    """Round 6: the value launches pick their tile geometry from a measured table (udf_mlp_kernel.inc:launch_mlp_fs2_mode: 16- / 32- / 48- / 64-point tiles
+    as one 8-wave workgroup per CU, 48- / 64-point tiles as two 4-wave workgroups per CU, the 8-wave forms again in three rounds).  Every geometry sums
+    in the same K order: a point's udf is the same bit for bit whichever launch size carries it - both sides of every boundary of the table, ragged
+    last tiles included."""
     from test_gpu_parity import mk
     from oracle import emap_oracle as O
     net, state, cfg = mk("d8w256L10", prec)
     gen = torch.Generator().manual_seed(123)
-    x = (torch.rand(20000, 3, generator=gen) * 2.4 - 1.2).to(DEV)
+    x = (torch.rand(70000, 3, generator=gen) * 2.4 - 1.2).to(DEV)
     with torch.no_grad():
-        base = net.hip_udf(x[:4096])[0].clone()                  # 128 tiles of 32: one 8-wave workgroup per CU on 32-point tiles
-        full = net.hip_udf(x)[0].clone()                         # 20 000 points: 4-wave workgroups, 32-point tiles
-        for P in (8192, 8193, 8256, 10240, 12345, 16321, 16384, 16385):
+        base = net.hip_udf(x[:4096])[0].clone()                  # 16-point tiles, one 8-wave workgroup per CU
+        full = net.hip_udf(x)[0].clone()                         # 70 000 points: 64-point tiles, 4-wave workgroups
+        for P in (4097, 8192, 8193, 8256, 10240, 12288, 12289, 12345, 16321, 16384, 16385, 20001, 24576, 24577, 32768, 32769, 36864, 36865, 49152, 49153):
             u = net.hip_udf(x[:P])[0]
             assert u.shape == (P, 1)
             assert torch.equal(u[:4096], base) and torch.equal(u, full[:P]), P
