@@ -612,8 +612,10 @@ static std::atomic<int> g_grad_mode{grad_mode_from_env()};   // process-wide; at
 int set_grad_mode(int mode) { return g_grad_mode.exchange((mode == 0 || mode == 1) ? mode : -1, std::memory_order_relaxed); }
 static int mlp_variant(const NetLayout& L, int prec, int64_t P, bool grad) {
     // reverse mode halves the MFMA work of a grad launch but a tile is two dependent sweeps: it wins once most CUs have a
-    // workgroup (measured crossover: the split modes between 8k and 12k points, single-pass modes at 16k).
-    const int64_t rev_min = (prec == EMAP_PREC_F16X3 || prec == EMAP_PREC_F16X3M || prec == EMAP_PREC_F16X3E || prec == EMAP_PREC_BF16X3) ? 10240 : 16384;
+    // workgroup (measured crossover: the split modes between 8k and 12k points, single-pass modes at 16k).  Round 6 (scripts/r6/gpu_grad_mode_sweep.py,
+    // profiles/r06_grad_mode_sweep.txt): the forward-mode kernel (16 points per workgroup, two per CU) starts its second round at 8 193 points - 129 us
+    // against the reverse sweep's 94 from there on (85 against 94 at 8 192): the split modes switch at 8 193 (rounds 3-5: 10 240).
+    const int64_t rev_min = (prec == EMAP_PREC_F16X3 || prec == EMAP_PREC_F16X3M || prec == EMAP_PREC_F16X3E || prec == EMAP_PREC_BF16X3) ? 8193 : 16384;
     const int gm = g_grad_mode.load(std::memory_order_relaxed);
     if (grad && L.has_rev && gm != 0 && (P >= rev_min || gm == 1)) return 3;
     return 2;

@@ -76,7 +76,7 @@ int emap_abi_version(void);
 const char* emap_last_error(void);
 
 /* How UDFNetwork.gradient (udf_model.py:121-135) is evaluated, process-wide: -1 (default) = by launch size (reverse sweep from
- * 10 240 points in the split modes / 16 384 in the single-pass modes, forward-mode tangents below), 0 = always forward-mode tangents,
+ * 8 193 points in the split modes (round 6; 10 240 before) / 16 384 in the single-pass modes, forward-mode tangents below), 0 = always forward-mode tangents,
  * 1 = always the reverse sweep.  Read ONCE at library load from EMAP_GRAD_MODE=fwd|rev; this call changes it afterwards (tests, A/B
  * measurements).  Returns the previous setting.  Not a per-launch environment lookup any more (ABI 6). */
 int emap_set_grad_mode(int mode);
@@ -199,7 +199,7 @@ int emap_composite_fwd_p(const float* rays_o, const float* rays_d, const float* 
 int emap_set_fused_sampling(int on);
 /* ABI v9: emap_render_fwd composites every ray INSIDE the final value + grad_x launch (the workgroup that writes a ray's last point runs
  * render_core's tail for it, udf_renderer_blending.py:463-625; BASELINE config C2: "fused MLP + composite kernel") whenever that launch is
- * the reverse-sweep kernel (>= 10 240 points in the split modes); only the deterministic cross-ray reduction stays a launch of its own.
+ * the reverse-sweep kernel (>= 8 193 points in the split modes); only the deterministic cross-ray reduction stays a launch of its own.
  * 0 restores the separate compositing launch (same results bit for bit: tests, A/B; EMAP_FUSED_COMPOSITE=0 at load).  Process-wide;
  * returns the previous value. */
 int emap_set_fused_composite(int on);
