@@ -13,7 +13,7 @@ res = {}
 for rnd in range(2):
     for name, code in geoms.items():
         env = dict(os.environ, EMAP_FS2_GEOM=code, EMAP_HIP_LIB=os.path.join(ROOT, "emap_amd/lib/geom/libemap_hip.so"))
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts/gpu_time_value_sweep.py"), "f16x3"] + Ps, env=env, capture_output=True, text=True)
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts/gpu_time_value_sweep.py"), os.environ.get("PREC", "f16x3")] + Ps, env=env, capture_output=True, text=True)
         line = [l for l in out.stdout.splitlines() if l.startswith("{")]
         if not line:
             print(name, "FAILED", out.stderr[-400:], file=sys.stderr)
