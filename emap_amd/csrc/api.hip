@@ -208,6 +208,9 @@ static int fused_composite_from_env() {
     return (e && e[0] == '0') ? 0 : 1;
 }
 static std::atomic<int> g_fused_composite{fused_composite_from_env()};
+#ifndef EMAP_FUSED_REDUCE
+#define EMAP_FUSED_REDUCE 1     // the fused tail also runs the cross-ray reduction (CompositeFuse::done_cnt); 0: composite_reduce_kernel as a launch of its own (A/B)
+#endif
 
 static Workspace plan_workspace(const EmapRenderParams& p, const NetLayout* L = nullptr) {
     const size_t N = (size_t)std::max(p.n_rays, 0);
@@ -224,7 +227,7 @@ static Workspace plan_workspace(const EmapRenderParams& p, const NetLayout* L = 
     w.z_new2 = off; off += align256(N * (size_t)std::max(m, 1) * 4);
     w.udf_new = off; off += align256(N * (size_t)std::max(m, 1) * 4);
     w.partials = off; off += align256(N * 8 * 4);
-    w.ray_cnt = off; off += align256(N * 4);      // arrival counters of the fused compositing tail (int32 per ray)
+    w.ray_cnt = off; off += align256((N + 1) * 4);      // arrival counters of the fused compositing tail (int32 per ray) + the launch's count of composited rays
     w.rev = off; off += L ? align256(rev_scratch_bytes(*L)) : 0;   // sigma' slabs of the reverse-mode value+gradient kernel
     w.total = off;
     return w;
@@ -400,7 +403,7 @@ int emap_render_fwd(const EmapNetConfig* cfg, const void* packed, int prec, cons
         // no up-sampling: the coarse samples (render() :700-720) are the final z_vals
         rc = launch_coarse(near, far, t_rand, N, Sc, z_vals, sample_dist, st);
         if (rc) return rc;
-        if (fuse_comp && hipMemsetAsync(ray_cnt, 0, (size_t)N * 4, st) != hipSuccess) { (void)hipGetLastError(); set_error("render_fwd: memset failed"); return EMAP_E_LAUNCH; }
+        if (fuse_comp && hipMemsetAsync(ray_cnt, 0, ((size_t)N + 1) * 4, st) != hipSuccess) { (void)hipGetLastError(); set_error("render_fwd: memset failed"); return EMAP_E_LAUNCH; }
     } else {
         // importance_sample (:802-841) in 2*steps launches: the coarse z_vals are evaluated where they are consumed (the first
         // MLP pass and the first sampler step, same separately rounded expression), every later sampler step merges the previous
@@ -409,7 +412,7 @@ int emap_render_fwd(const EmapNetConfig* cfg, const void* packed, int prec, cons
         memset(&src, 0, sizeof(src));
         src.rays_o = rays_o; src.rays_d = rays_d; src.n_per_ray = Sc; src.mid = 0; src.sample_dist = sample_dist;
         src.coarse = 1; src.near = near; src.far = far; src.t_rand = t_rand;
-        if (fuse_comp) { src.zero_cnt = ray_cnt; src.zero_n = N; }
+        if (fuse_comp) { src.zero_cnt = ray_cnt; src.zero_n = N + 1; }
         rc = launch_mlp(L, packed, prec, src, (int64_t)N * Sc, ubuf[0], nullptr, st, err_flags);
         if (rc) return rc;
         src.coarse = 0; src.zero_cnt = nullptr; src.zero_n = 0;
@@ -461,13 +464,15 @@ int emap_render_fwd(const EmapNetConfig* cfg, const void* packed, int prec, cons
                                  partials, &cf.c);
         if (rc) return rc;
         cf.ray_cnt = ray_cnt;
+        cf.done_cnt = EMAP_FUSED_REDUCE ? ray_cnt + N : nullptr;
     }
     {
         ProfScope ps(0, st);
         rc = launch_mlp(L, packed, prec, fin, (int64_t)N * S, udf, grad3, st, err_flags, ws + w.rev, fuse_comp ? &cf : nullptr);
     }
     if (rc) return rc;
-    if (fuse_comp) return launch_composite_reduce(cf.c, err_flags, st);      // 4 launches per render: value pass, importance_sample, value + grad_x + compositing, reduction
+    // 3 launches per render: value pass, importance_sample, value + grad_x + compositing + cross-ray reduction (-DEMAP_FUSED_REDUCE=0: the reduction as a fourth)
+    if (fuse_comp) return (cf.done_cnt && cf.c.out.scalars) ? EMAP_OK : launch_composite_reduce(cf.c, err_flags, st);
     return launch_composite(rays_o, rays_d, z_vals, udf, grad3, depth_scale, N, S, sample_dist, p->inv_s, p->beta, p->gamma,
                             p->cos_anneal_ratio, p->has_cos_anneal, p->flip_saturation, p->near_surface, p->sparse_scale,
                             p->background, p->has_background, p->variance_dev, p->beta_dev, p->gamma_dev, p->beta_min, out,

@@ -156,6 +156,9 @@ struct CompositeArgs {
 struct CompositeFuse {
     CompositeArgs c;
     int32_t* ray_cnt;
+    // rays composited so far in this launch (zeroed with ray_cnt), or null.  Not null: the workgroup whose rays bring it to c.N also runs the
+    // deterministic cross-ray reduction (composite_reduce_body, the body of composite_reduce_kernel): the render ends with this launch.
+    int32_t* done_cnt;
 };
 // upper bound on the rays ONE workgroup of the value + grad_x kernel can come to own (its list lives in the kernel's exchange buffer): every tile
 // it runs (64 points, <= 512 workgroups) can complete at most 64 / S + 2 rays

@@ -187,8 +187,6 @@ __global__ __launch_bounds__(256) void coarse_z_kernel(const float* near, const 
 // ---------------------------------------------------------------------------------------------
 #include "composite_dev.inc"     // CompositeArgs + composite_ray<C, COH>: the per-ray body, shared with udf_mlp_rev32.inc's fused tail
 
-__device__ void composite_reduce_body(const float* partials, int N, float* scalars, int32_t* err, const CompositeArgs& a, int tid, int nthreads,
-                                      double (*red)[5]);
 
 template <int C>
 __global__ __launch_bounds__(64) void composite_kernel(const CompositeArgs a) {
@@ -196,48 +194,10 @@ __global__ __launch_bounds__(64) void composite_kernel(const CompositeArgs a) {
 }
 
 // deterministic cross-ray reduction of the eikonal terms (:618-625) and sparse_error (:642-644)
-__device__ void composite_reduce_body(const float* partials, int N, float* scalars, int32_t* err, const CompositeArgs& a, int tid, int nthreads,
-                                      double (*red)[5]) {
-    const int nw = nthreads >> 6;
-    double v[5] = {0, 0, 0, 0, 0};
-    typedef float f4 __attribute__((ext_vector_type(4)));
-    for (int i = tid; i < N; i += nthreads) {
-        const f4 lo = *reinterpret_cast<const f4*>(partials + (size_t)i * 8);
-        const float hi = partials[(size_t)i * 8 + 4];
-        v[0] += (double)lo[0]; v[1] += (double)lo[1]; v[2] += (double)lo[2]; v[3] += (double)lo[3]; v[4] += (double)hi;
-    }
-#pragma unroll
-    for (int k = 0; k < 5; ++k) v[k] = wave_sum_d(v[k]);
-    if ((tid & 63) == 0)
-#pragma unroll
-        for (int k = 0; k < 5; ++k) red[tid >> 6][k] = v[k];
-    __syncthreads();
-    if (tid == 0) {
-        double t[5];
-        for (int k = 0; k < 5; ++k) { t[k] = 0; for (int q = 0; q < nw; ++q) t[k] += red[q][k]; }
-        const float e_rel = (float)t[0], c_rel = (float)t[1], e_ns = (float)t[2], c_ns = (float)t[3];
-        const float ge = FDIV(e_rel, FADD(c_rel, 1e-5f));
-        scalars[0] = ge;
-        scalars[1] = FDIV(e_ns, FADD(c_ns, 1e-5f));
-        scalars[2] = (float)(t[4] / (double)N);
-        scalars[3] = e_rel; scalars[4] = c_rel; scalars[5] = e_ns; scalars[6] = c_ns; scalars[7] = (float)t[4];
-        // s_val = 1/inv_s, 1/beta, gamma: the "variance"/"beta"/"gamma" entries of the render dict (:656-658)
-        float inv_s_ = a.inv_s, beta_ = a.beta, gamma_ = a.gamma;
-        if (a.var_p) {
-            inv_s_ = clipf(expf(FMUL(a.var_p[0], 10.0f)), 1e-6f, 1e6f);
-            beta_ = clipf(clipf(expf(FMUL(a.beta_p[0], 10.0f)), 0.0f, FDIV(1.0f, a.beta_min)), 1e-6f, 1e6f);
-            gamma_ = clipf(expf(FMUL(a.gamma_p[0], 10.0f)), 1e-6f, 1e6f);
-        }
-        scalars[8] = FDIV(1.0f, inv_s_); scalars[9] = FDIV(1.0f, beta_); scalars[10] = gamma_; scalars[11] = inv_s_;
-        if (err && ge != ge) atomicOr(err, EMAP_F_NAN_GRADERR);
-    }
-}
-
-// deterministic cross-ray reduction of the eikonal terms (:618-625) and sparse_error (:642-644)
 __global__ __launch_bounds__(256) void composite_reduce_kernel(const float* partials, int N, float* scalars, int32_t* err,
                                                                const CompositeArgs a) {
     __shared__ double red[4][5];
-    composite_reduce_body(partials, N, scalars, err, a, threadIdx.x, 256, red);
+    composite_reduce_body<false>(partials, N, scalars, err, a, threadIdx.x, 256, red);
 }
 
 // ---------------------------------------------------------------------------------------------
