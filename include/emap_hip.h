@@ -199,8 +199,9 @@ int emap_composite_fwd_p(const float* rays_o, const float* rays_d, const float* 
 int emap_set_fused_sampling(int on);
 /* ABI v9: emap_render_fwd composites every ray INSIDE the final value + grad_x launch (the workgroup that writes a ray's last point runs
  * render_core's tail for it, udf_renderer_blending.py:463-625; BASELINE config C2: "fused MLP + composite kernel") whenever that launch is
- * the reverse-sweep kernel (>= 8 193 points in the split modes); only the deterministic cross-ray reduction stays a launch of its own.
- * 0 restores the separate compositing launch (same results bit for bit: tests, A/B; EMAP_FUSED_COMPOSITE=0 at load).  Process-wide;
+ * the reverse-sweep kernel (>= 8 193 points in the split modes); the workgroup that composites the render's last ray then runs the
+ * deterministic cross-ray reduction too (same additions in the same order as composite_reduce_kernel): the render ends with that launch.
+ * 0 restores the separate compositing and reduction launches (same results bit for bit: tests, A/B; EMAP_FUSED_COMPOSITE=0 at load).  Process-wide;
  * returns the previous value. */
 int emap_set_fused_composite(int on);
 /* ABI v10: 1 = the wide value launches (the coarse pass of a render: UDFNetwork.udf on n_samples points per ray, udf_renderer_blending.py:722-725,
