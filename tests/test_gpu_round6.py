@@ -461,3 +461,37 @@ def test_hip_training_run_matches_the_reference_trained_model_on_a_held_out_view
     assert rms <= 0.04
     assert float(r.deviation_network.variance) == pytest.approx(float(g["variance"]), rel=5e-2)
     assert float(r.beta_network.beta) == pytest.approx(float(g["beta"]), rel=5e-2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec,tol", [("f16x3", 5e-5), ("f16x3e", 2e-5), ("bf16x3", 1e-4), ("f16", 5e-3)])
+@pytest.mark.parametrize("skip_in", [(4,), (7,)])
+def test_reverse_sweep_with_and_without_the_fused_output_layer_vs_forward_mode_tangents(prec, tol, skip_in):
+    """udf_mlp_rev32_kernel applies the output layer and forms the reverse sweep's first delta_z inside the LAST hidden layer's epilogue (LASTH,
+    udf_mlp_rev32.inc) when that layer is an ordinary one - skip_in = (4,), the reference's network (udf_model.py:24-45).  With the skip connection
+    feeding the last hidden layer (skip_in = (7,)) the layer reads the PE block, LASTH does not apply and the kernel takes the path of rounds 3-6a
+    (output layer as a K-split GEMM, sigma' of that layer through the stash).  Both against the forward-mode tangent kernel (itself pinned by g2 and
+    the oracle) at launch sizes with one and with several tiles per workgroup, bit-stable run to run."""
+    kw = dict(d_in=3, d_out=1, d_hidden=256, n_layers=8, skip_in=skip_in, multires=10, bias=0.5)
+    state = synthetic.make_udf_state(seed=77, pert=0.02, **kw)
+    net = emap_amd.UDFNetwork(scale=1.0, precision=prec, **kw)
+    net.load_state_dict(state)
+    net = net.to(DEV)
+    gen = torch.Generator().manual_seed(9)
+    x = (torch.rand(65536 + 4099, 3, generator=gen) * 2 - 1).to(DEV)
+    L = _lib.lib()
+    for P in (16384, 65536 + 4099):
+        xp = x[:P].contiguous()
+        with torch.no_grad():
+            old = L.emap_set_grad_mode(1)
+            try:
+                u, g = net.hip_udf(xp, with_grad=True)
+                u2, g2 = net.hip_udf(xp, with_grad=True)
+                L.emap_set_grad_mode(0)
+                uf, gf = net.hip_udf(xp[:16384].contiguous(), with_grad=True)
+            finally:
+                L.emap_set_grad_mode(old)
+        assert torch.equal(u, u2) and torch.equal(g, g2)
+        du = float((u[:16384] - uf).abs().max() / uf.abs().max())
+        dg = float((g[:16384] - gf).abs().max() / gf.abs().max())
+        assert du <= tol and dg <= tol, (skip_in, prec, P, du, dg)
